@@ -1,0 +1,186 @@
+/* pm.h — C ABI of the MI355X-native two-view point matcher (libpm_hip.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of wenxiaoshuai/Points-Matching:
+ *   descriptor match  ->  strong-match filter  ->  point gather  ->  robust F  ->  residual report
+ * i.e. `Points Matching/main.cpp:42-46, 49-69, 71-79, 89-91, 95-98, 103-123` (cited per entry
+ * point below as main.cpp:N).  The reference has no FFI of its own: its boundary is the two
+ * OpenCV call sites (main.cpp:46, main.cpp:95-98) plus the glue around them, so every symbol
+ * here replaces one of those call sites or glue blocks.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++/torch types; every function returns a pm_status
+ *     (0 = ok, <0 = error) and never throws across the boundary (the reference's OpenCV calls
+ *     raise cv::Exception instead).
+ *   - caller owns every buffer; the library owns only the context's scratch arena.
+ *   - a context is bound to one HIP device + one HIP stream and is NOT thread-safe; distinct
+ *     contexts are independent.
+ *   - functions without a `_dev` suffix take HOST pointers and block until the result is in
+ *     the caller's buffers.  `_dev` variants take DEVICE pointers (hipMalloc'd / torch
+ *     tensor .data_ptr()), enqueue on the context's stream and return without synchronising;
+ *     call pm_ctx_synchronize() (or synchronise the stream you attached) before reading.
+ *   - exact arithmetic (op order, tie rules, RNG) is frozen in docs/SPEC.md.
+ */
+#ifndef PM_H_
+#define PM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PM_VERSION_MAJOR 0
+#define PM_VERSION_MINOR 1
+
+/* ---- status codes ------------------------------------------------------------------------- */
+typedef enum pm_status {
+    PM_OK            =  0,
+    PM_E_INVALID     = -1,  /* bad argument (null pointer, negative size, k out of range ...)   */
+    PM_E_TOO_FEW     = -2,  /* fewer than 8 correspondences (cv::findFundamentalMat: count<7 fails) */
+    PM_E_NO_MODEL    = -3,  /* every hypothesis in the range was degenerate; F = 0, mask = 0     */
+    PM_E_HIP         = -4,  /* a HIP runtime call failed; see pm_last_error()                    */
+    PM_E_NOMEM       = -5,
+    PM_E_UNSUPPORTED = -6
+} pm_status;
+
+/* One match record.  Mirrors cv::DMatch (OpenCV 2.4: {int queryIdx; int trainIdx; int imgIdx;
+ * float distance;}) as used at main.cpp:45, :54-55, :65, :76-78, :110, :113.  16 bytes. */
+typedef struct pm_match {
+    int32_t queryIdx;
+    int32_t trainIdx;   /* -1 when fewer than k train rows exist */
+    int32_t imgIdx;     /* always 0 (single train image, as in main.cpp:46) */
+    float   distance;   /* L2: sqrt of the squared distance; Hamming: bit count as float */
+} pm_match;
+
+typedef struct pm_ctx pm_ctx;   /* opaque */
+
+/* ---- context -------------------------------------------------------------------------------
+ * Replaces the implicit OpenCV global state behind main.cpp:44-46 / :95-98. */
+int  pm_ctx_create(int device, pm_ctx** out);
+int  pm_ctx_destroy(pm_ctx* ctx);
+/* Attach an externally owned hipStream_t (passed as void*); NULL restores the context's own
+ * stream.  Lets a caller time the kernels with events on its own stream. */
+int  pm_ctx_set_stream(pm_ctx* ctx, void* hip_stream);
+int  pm_ctx_synchronize(pm_ctx* ctx);
+/* Per-kernel timing with hipEvents on the context's stream.  enable!=0 starts collecting.
+ * pm_ctx_timing_get: mean milliseconds and launch count of the named kernel since the last
+ * pm_ctx_timing_reset (synchronises the stream).  Names: "knn_l2_mfma", "knn_l2_refine",
+ * "knn_l2_exact", "knn_l2_prep", "knn_hamming", "ransac_solve", "ransac_score",
+ * "ransac_select", "ransac_final". */
+int  pm_ctx_timing_enable(pm_ctx* ctx, int enable);
+int  pm_ctx_timing_reset(pm_ctx* ctx);
+int  pm_ctx_timing_get(pm_ctx* ctx, const char* kernel, double* mean_ms, int* launches);
+const char* pm_last_error(void);       /* thread-local text of the last PM_E_HIP / PM_E_* */
+const char* pm_status_string(int status);
+int  pm_version(void);                 /* major*100 + minor */
+
+/* ---- descriptor matching (replaces main.cpp:46 `matcher.match(imageDesc1, imageDesc2, ...)`,
+ *      matcher = BruteForceMatcher<L2<float>> of the commented main.cpp:43, generalised to k-NN)
+ *
+ * q: nq x dim row-major float (imageDesc1), t: nt x dim row-major float (imageDesc2).
+ * out: nq*k records, row i at out[i*k .. i*k+k-1], ascending by (distance bits, trainIdx):
+ *      smaller distance first, equal distances -> lower trainIdx first (SPEC S3).
+ *      If nt < k the tail of each row has trainIdx = -1, distance = +inf.
+ * 1 <= k <= PM_MAX_K.  nq == 0 is ok (no output).  nt == 0 gives all -1 rows.
+ * `flags`: 0 = automatic (MFMA coarse pass + canonical refinement when dim%8==0 && dim<=128 &&
+ *          k<=2, exact kernel otherwise); PM_KNN_FORCE_EXACT = always the exact VALU kernel.
+ *          Both produce bit-identical output (tests assert it). */
+#define PM_MAX_K 16
+#define PM_KNN_FORCE_EXACT 1
+int pm_bf_knn_l2_f32(pm_ctx* ctx, const float* q, int nq, const float* t, int nt,
+                     int dim, int k, int flags, pm_match* out);
+int pm_bf_knn_l2_f32_dev(pm_ctx* ctx, const float* d_q, int nq, const float* d_t, int nt,
+                         int dim, int k, int flags, pm_match* d_out);
+
+/* Binary descriptors (ORB-256 = 32 bytes/row): Hamming distance, popcount of XOR.
+ * `bytes` must be a multiple of 4.  Replaces main.cpp:46 for BASELINE config C4. */
+int pm_bf_knn_hamming_u8(pm_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt,
+                         int bytes, int k, pm_match* out);
+int pm_bf_knn_hamming_u8_dev(pm_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt,
+                             int bytes, int k, pm_match* d_out);
+
+/* ---- strong-match filters (the slot of main.cpp:49-69) -------------------------------------
+ * Host-side, O(n).  `out` must hold n (resp. nq) records; survivors keep query order. */
+
+/* Literal main.cpp:49-69: minMatch starts at 1, maxMatch at 0 (main.cpp:49-50); keep i iff
+ * (double)distance < minMatch + (maxMatch - minMatch) / 2  (strict, in double, main.cpp:65).
+ * min_out/max_out receive the two values the reference prints at main.cpp:58-59. */
+int pm_filter_midpoint(const pm_match* m, int n, double* min_out, double* max_out,
+                       pm_match* out, int* n_out);
+/* Ratio test on k-NN rows (k >= 2): keep row i iff knn[i*k+1].trainIdx >= 0 and
+ * knn[i*k].distance < ratio * knn[i*k+1].distance (float multiply, strict).  Emits knn[i*k]. */
+int pm_filter_ratio(const pm_match* knn, int nq, int k, float ratio, pm_match* out, int* n_out);
+
+/* ---- match list + gather (main.cpp:71-79, :89-91) ------------------------------------------
+ * pm_match_indices: pointIndexes1/2 of main.cpp:77-78.
+ * pm_gather_points: KeyPoint::convert(keyPoint, selPoints, pointIndexes) of main.cpp:90-91;
+ *   kp_xy is the keypoints' .pt as interleaved (x,y) floats; out_xy[i] = kp_xy[idx[i]].
+ *   Returns PM_E_INVALID if an index is outside [0, n_kp). */
+int pm_match_indices(const pm_match* m, int n, int32_t* query_idx, int32_t* train_idx);
+int pm_gather_points(const float* kp_xy, int n_kp, const int32_t* idx, int n, float* out_xy);
+/* Formats the stdout block of main.cpp:73-76 into buf (NUL-terminated, truncated at cap);
+ * returns the number of bytes that the full text needs (like snprintf). */
+long pm_format_match_list(const pm_match* m, int n, char* buf, size_t cap);
+
+/* ---- robust fundamental matrix (replaces main.cpp:95-98 cv::findFundamentalMat) ------------ */
+enum { PM_ERR_SAMPSON = 0, PM_ERR_SYM_EPIPOLAR = 1 };
+
+typedef struct pm_ransac_params {
+    int64_t  hyp_begin;     /* hypothesis ids [hyp_begin, hyp_end) are evaluated; ids < 2^32  */
+    int64_t  hyp_end;       /* single GPU: 0 .. iters.  Multi-GPU: this rank's shard.          */
+    uint64_t seed;          /* counter-based sampler key (SPEC S6): sample(h) depends only on  */
+                            /* (seed, h, n), never on the shard or the device                   */
+    float    thresh_px;     /* inlier threshold tau in pixels; test is num^2 <= tau^2 * den     */
+    int32_t  error_kind;    /* PM_ERR_SAMPSON | PM_ERR_SYM_EPIPOLAR                             */
+} pm_ransac_params;
+
+/* xy1/xy2: n x 2 interleaved float pixel coordinates in match order (selPoints1/2 of
+ * main.cpp:89-91).  Every hypothesis h in the range: sample 8 correspondences, Hartley-
+ * normalised 8-point solve with rank-2 enforcement (fp64), score ALL n correspondences (fp32),
+ * count inliers.  Winner: most inliers, ties -> lowest h.
+ *   best_key : (inliers << 32) | (0xFFFFFFFF - h); 0 = no valid model in the range.  This is
+ *              the value a multi-GPU caller max-reduces (one 8-byte all-reduce).
+ *   F        : 3x3 row-major, x2^T F x1 = 0, unit Frobenius norm, F[8] >= 0 (may be NULL)
+ *   mask     : n bytes 0/1 (may be NULL);  n_inliers: may be NULL.
+ * n < 8 -> PM_E_TOO_FEW.  All-degenerate range -> PM_E_NO_MODEL with F = 0, mask = 0. */
+int pm_ransac_fundamental(pm_ctx* ctx, const float* xy1, const float* xy2, int n,
+                          const pm_ransac_params* p, double F[9], uint8_t* mask,
+                          int* n_inliers, uint64_t* best_key);
+/* Device-resident form used by the bench and the multi-GPU path: scores the shard and leaves
+ * the shard's best key in *d_best_key (device uint64).  No model is materialised. */
+int pm_ransac_score_dev(pm_ctx* ctx, const float* d_xy1, const float* d_xy2, int n,
+                        const pm_ransac_params* p, uint64_t* d_best_key);
+/* Re-derives F + mask of ONE hypothesis id (every rank calls this with the reduced winner:
+ * no model broadcast is needed).  hyp is the id, not the key. */
+int pm_ransac_model_from_hyp(pm_ctx* ctx, const float* xy1, const float* xy2, int n,
+                             const pm_ransac_params* p, int64_t hyp, double F[9],
+                             uint8_t* mask, int* n_inliers);
+/* key helpers */
+static inline uint64_t pm_ransac_key(uint32_t inliers, uint32_t hyp) {
+    return ((uint64_t)inliers << 32) | (uint64_t)(0xFFFFFFFFu - hyp);
+}
+static inline uint32_t pm_ransac_key_hyp(uint64_t key)     { return 0xFFFFFFFFu - (uint32_t)key; }
+static inline uint32_t pm_ransac_key_inliers(uint64_t key) { return (uint32_t)(key >> 32); }
+
+/* ---- residual report (main.cpp:103-123) -----------------------------------------------------
+ * r[i] = [xa ya 1] * F * [xb yb 1]^T in fp64.  transposed != 0 reproduces the reference
+ * literally ((xa,ya) = image-1 point, (xb,yb) = image-2 point: x1^T F x2, main.cpp:110-117);
+ * transposed == 0 evaluates x2^T F x1.  mean_abs = sum|r| / n (main.cpp:120,123).
+ * pm_f_scale_f33: rescales F so F[8] == 1 when |F[8]| > DBL_EPSILON (OpenCV's output scale,
+ * which the magnitudes printed at main.cpp:119 depend on). */
+int pm_epipolar_residuals(const float* xy1, const float* xy2, int n, const double F[9],
+                          int transposed, double* r, double* mean_abs);
+int pm_f_scale_f33(double F[9]);
+
+/* ---- epipolar lines (main.cpp:127-142) ----------------------------------------
+ * cv::computeCorrespondEpilines(pts, which_image, F, lines): l = F*x (which_image==1) or
+ * F^T*x (==2), scaled so a^2+b^2 = 1; lines: n x 3 floats.  pm_epiline_endpoints: the two
+ * cv::Point arguments of main.cpp:138-140 for an image `cols` wide (float->int truncation). */
+int pm_epilines(const float* xy, int n, int which_image, const double F[9], float* lines);
+int pm_epiline_endpoints(const float* lines, int n, int cols, int32_t* xyxy);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PM_H_ */
