@@ -1,0 +1,271 @@
+"""Python mirror of include/pm.h over ctypes (plumbing for tests and bench.py, not the product).
+
+The product is libpm_hip.so (HIP kernels behind a C ABI) driven by the C++ host in host/;
+this module only forwards numpy arrays / torch device pointers to that ABI.  There is NO CPU
+fallback: if the library is missing or a call fails, PmError is raised.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpm_hip.so")
+
+MATCH_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"),
+                        ("distance", "<f4")])
+PM_MAX_K = 16
+PM_KNN_FORCE_EXACT = 1
+PM_ERR_SAMPSON = 0
+PM_ERR_SYM_EPIPOLAR = 1
+PM_OK, PM_E_INVALID, PM_E_TOO_FEW, PM_E_NO_MODEL, PM_E_HIP, PM_E_NOMEM, PM_E_UNSUPPORTED = \
+    0, -1, -2, -3, -4, -5, -6
+
+# every extern "C" symbol include/pm.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "pm_ctx_create", "pm_ctx_destroy", "pm_ctx_set_stream", "pm_ctx_synchronize",
+    "pm_ctx_timing_enable", "pm_ctx_timing_reset", "pm_ctx_timing_get", "pm_last_error",
+    "pm_status_string", "pm_version",
+    "pm_bf_knn_l2_f32", "pm_bf_knn_l2_f32_dev", "pm_bf_knn_hamming_u8", "pm_bf_knn_hamming_u8_dev",
+    "pm_filter_midpoint", "pm_filter_ratio", "pm_match_indices", "pm_gather_points",
+    "pm_format_match_list",
+    "pm_ransac_fundamental", "pm_ransac_score_dev", "pm_ransac_model_from_hyp",
+    "pm_epipolar_residuals", "pm_f_scale_f33", "pm_epilines", "pm_epiline_endpoints",
+]
+
+
+class PmError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("pm status %d: %s" % (status, msg))
+        self.status = status
+
+
+class RansacParams(C.Structure):
+    _fields_ = [("hyp_begin", C.c_int64), ("hyp_end", C.c_int64), ("seed", C.c_uint64),
+                ("thresh_px", C.c_float), ("error_kind", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    """Loads libpm_hip.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PmError(PM_E_UNSUPPORTED,
+                          "%s is missing: run `python -m points_matching_amd.build`" % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.pm_last_error.restype = C.c_char_p
+        _lib.pm_status_string.restype = C.c_char_p
+        _lib.pm_format_match_list.restype = C.c_long
+    return _lib
+
+
+def _check(rc):
+    if rc != PM_OK:
+        raise PmError(rc, (lib().pm_last_error() or b"").decode() or
+                      lib().pm_status_string(rc).decode())
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def ransac_key(inliers, hyp):
+    return (int(inliers) << 32) | (0xFFFFFFFF - int(hyp))
+
+
+def ransac_key_hyp(key):
+    return 0xFFFFFFFF - (int(key) & 0xFFFFFFFF)
+
+
+def ransac_key_inliers(key):
+    return int(key) >> 32
+
+
+# ---- host-side stages (no GPU needed) ---------------------------------------------------------
+
+def filter_midpoint(m):
+    """main.cpp:49-69.  Returns (good, minMatch, maxMatch)."""
+    m = np.ascontiguousarray(m, MATCH_DTYPE).reshape(-1)
+    out = np.zeros(max(m.size, 1), MATCH_DTYPE)
+    mn, mx, n = C.c_double(), C.c_double(), C.c_int()
+    _check(lib().pm_filter_midpoint(_p(m), m.size, C.byref(mn), C.byref(mx), _p(out), C.byref(n)))
+    return out[:n.value].copy(), mn.value, mx.value
+
+
+def filter_ratio(knn, ratio):
+    knn = np.ascontiguousarray(knn, MATCH_DTYPE)
+    nq, k = knn.shape
+    out = np.zeros(max(nq, 1), MATCH_DTYPE)
+    n = C.c_int()
+    _check(lib().pm_filter_ratio(_p(knn), nq, k, C.c_float(ratio), _p(out), C.byref(n)))
+    return out[:n.value].copy()
+
+
+def match_indices(m):
+    m = np.ascontiguousarray(m, MATCH_DTYPE).reshape(-1)
+    qi = np.zeros(m.size, np.int32)
+    ti = np.zeros(m.size, np.int32)
+    _check(lib().pm_match_indices(_p(m), m.size, _p(qi), _p(ti)))
+    return qi, ti
+
+
+def gather_points(kp_xy, idx):
+    kp_xy = np.ascontiguousarray(kp_xy, np.float32).reshape(-1, 2)
+    idx = np.ascontiguousarray(idx, np.int32)
+    out = np.zeros((idx.size, 2), np.float32)
+    _check(lib().pm_gather_points(_p(kp_xy), kp_xy.shape[0], _p(idx), idx.size, _p(out)))
+    return out
+
+
+def format_match_list(m):
+    m = np.ascontiguousarray(m, MATCH_DTYPE).reshape(-1)
+    need = lib().pm_format_match_list(_p(m), m.size, None, C.c_size_t(0))
+    buf = C.create_string_buffer(need + 1)
+    lib().pm_format_match_list(_p(m), m.size, buf, C.c_size_t(need + 1))
+    return buf.value.decode()
+
+
+def epipolar_residuals(xy1, xy2, F, transposed=1):
+    xy1 = np.ascontiguousarray(xy1, np.float32)
+    xy2 = np.ascontiguousarray(xy2, np.float32)
+    F = np.ascontiguousarray(F, np.float64).reshape(9)
+    n = xy1.shape[0]
+    r = np.zeros(max(n, 1), np.float64)
+    mean = C.c_double()
+    _check(lib().pm_epipolar_residuals(_p(xy1), _p(xy2), n, _p(F), transposed, _p(r), C.byref(mean)))
+    return r[:n], mean.value
+
+
+def f_scale_f33(F):
+    F = np.ascontiguousarray(F, np.float64).reshape(9).copy()
+    _check(lib().pm_f_scale_f33(_p(F)))
+    return F.reshape(3, 3)
+
+
+def epilines(xy, which_image, F):
+    xy = np.ascontiguousarray(xy, np.float32)
+    F = np.ascontiguousarray(F, np.float64).reshape(9)
+    lines = np.zeros((xy.shape[0], 3), np.float32)
+    _check(lib().pm_epilines(_p(xy), xy.shape[0], which_image, _p(F), _p(lines)))
+    return lines
+
+
+def epiline_endpoints(lines, cols):
+    lines = np.ascontiguousarray(lines, np.float32)
+    out = np.zeros((lines.shape[0], 4), np.int32)
+    _check(lib().pm_epiline_endpoints(_p(lines), lines.shape[0], cols, _p(out)))
+    return out
+
+
+# ---- GPU context ------------------------------------------------------------------------------
+
+class Context:
+    """pm_ctx wrapper: one HIP device + stream + scratch arena."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _check(lib().pm_ctx_create(device, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().pm_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_stream(self, stream_handle):
+        _check(lib().pm_ctx_set_stream(self._h, C.c_void_p(stream_handle or 0)))
+
+    def synchronize(self):
+        _check(lib().pm_ctx_synchronize(self._h))
+
+    def timing_enable(self, on=True):
+        _check(lib().pm_ctx_timing_enable(self._h, int(on)))
+
+    def timing_reset(self):
+        _check(lib().pm_ctx_timing_reset(self._h))
+
+    def timing_get(self, name):
+        ms, n = C.c_double(), C.c_int()
+        _check(lib().pm_ctx_timing_get(self._h, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # -- matcher (main.cpp:46) -------------------------------------------------------------------
+    def bf_knn_l2(self, q, t, k, flags=0):
+        q = np.ascontiguousarray(q, np.float32)
+        t = np.ascontiguousarray(t, np.float32)
+        dim = q.shape[1]
+        assert t.ndim == 2 and t.shape[1] == dim
+        out = np.zeros((q.shape[0], k), MATCH_DTYPE)
+        _check(lib().pm_bf_knn_l2_f32(self._h, _p(q), q.shape[0], _p(t), t.shape[0], dim, k, flags,
+                                      _p(out)))
+        return out
+
+    def bf_knn_l2_dev(self, dq_ptr, nq, dt_ptr, nt, dim, k, dout_ptr, flags=0):
+        _check(lib().pm_bf_knn_l2_f32_dev(self._h, C.c_void_p(dq_ptr), nq, C.c_void_p(dt_ptr), nt,
+                                          dim, k, flags, C.c_void_p(dout_ptr)))
+
+    def bf_knn_hamming(self, q, t, k):
+        q = np.ascontiguousarray(q, np.uint8)
+        t = np.ascontiguousarray(t, np.uint8)
+        nbytes = q.shape[1]
+        assert t.ndim == 2 and t.shape[1] == nbytes
+        out = np.zeros((q.shape[0], k), MATCH_DTYPE)
+        _check(lib().pm_bf_knn_hamming_u8(self._h, _p(q), q.shape[0], _p(t), t.shape[0], nbytes, k,
+                                          _p(out)))
+        return out
+
+    def bf_knn_hamming_dev(self, dq_ptr, nq, dt_ptr, nt, nbytes, k, dout_ptr):
+        _check(lib().pm_bf_knn_hamming_u8_dev(self._h, C.c_void_p(dq_ptr), nq, C.c_void_p(dt_ptr),
+                                              nt, nbytes, k, C.c_void_p(dout_ptr)))
+
+    # -- robust F (main.cpp:95-98) ---------------------------------------------------------------
+    def ransac_fundamental(self, xy1, xy2, iters, thresh_px, seed, kind=PM_ERR_SAMPSON,
+                           hyp_begin=0):
+        """Returns (status, F(3x3), mask, n_inliers, best_key); raises on anything other than
+        PM_OK / PM_E_NO_MODEL / PM_E_TOO_FEW (those are data outcomes, reported as status)."""
+        xy1 = np.ascontiguousarray(xy1, np.float32).reshape(-1, 2)
+        xy2 = np.ascontiguousarray(xy2, np.float32).reshape(-1, 2)
+        n = xy1.shape[0]
+        prm = RansacParams(hyp_begin, iters, seed, thresh_px, kind)
+        F = np.zeros(9, np.float64)
+        mask = np.zeros(max(n, 1), np.uint8)
+        ninl, key = C.c_int(), C.c_uint64()
+        rc = lib().pm_ransac_fundamental(self._h, _p(xy1), _p(xy2), n, C.byref(prm), _p(F), _p(mask),
+                                         C.byref(ninl), C.byref(key))
+        if rc not in (PM_OK, PM_E_NO_MODEL, PM_E_TOO_FEW):
+            _check(rc)
+        return rc, F.reshape(3, 3), mask[:n], ninl.value, key.value
+
+    def ransac_model_from_hyp(self, xy1, xy2, hyp, thresh_px, seed, kind=PM_ERR_SAMPSON):
+        xy1 = np.ascontiguousarray(xy1, np.float32).reshape(-1, 2)
+        xy2 = np.ascontiguousarray(xy2, np.float32).reshape(-1, 2)
+        n = xy1.shape[0]
+        prm = RansacParams(0, 0, seed, thresh_px, kind)
+        F = np.zeros(9, np.float64)
+        mask = np.zeros(max(n, 1), np.uint8)
+        ninl = C.c_int()
+        rc = lib().pm_ransac_model_from_hyp(self._h, _p(xy1), _p(xy2), n, C.byref(prm),
+                                            C.c_int64(hyp), _p(F), _p(mask), C.byref(ninl))
+        if rc not in (PM_OK, PM_E_NO_MODEL, PM_E_TOO_FEW):
+            _check(rc)
+        return rc, F.reshape(3, 3), mask[:n], ninl.value
+
+    def ransac_score_dev(self, dxy1_ptr, dxy2_ptr, n, hyp_begin, hyp_end, thresh_px, seed,
+                         dkey_ptr, kind=PM_ERR_SAMPSON):
+        prm = RansacParams(hyp_begin, hyp_end, seed, thresh_px, kind)
+        _check(lib().pm_ransac_score_dev(self._h, C.c_void_p(dxy1_ptr), C.c_void_p(dxy2_ptr), n,
+                                         C.byref(prm), C.c_void_p(dkey_ptr)))

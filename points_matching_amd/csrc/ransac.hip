@@ -1,0 +1,550 @@
+// ransac.hip — RANSAC fundamental-matrix estimation on gfx950 (MI355X).
+//
+// Replaces `cv::findFundamentalMat(Mat(selPoints1), Mat(selPoints2), CV_FM_7POINT)`
+// (main.cpp:95-98) by the estimator BASELINE.json names: H fixed hypotheses, each = sample 8
+// correspondences (counter-based sampler keyed by (seed, h): docs/SPEC.md S6), Hartley-normalised
+// 8-point solve with rank-2 enforcement in fp64 (S7), Sampson scoring of ALL n correspondences in
+// fp32 (S8), keep the hypothesis with most inliers, ties -> lowest h (S9).
+//
+//   ransac_solve   one lane per hypothesis: sampler + 8-point solve, F rounded to fp32
+//   ransac_score   lane = hypothesis (F in 9 VGPRs), correspondences are wave-uniform and arrive
+//                  as scalar operands; grid = hypothesis blocks x correspondence chunks, partial
+//                  inlier counts meet in one integer atomicAdd per (lane, chunk)
+//   ransac_select  key = (inliers << 32) | (0xFFFFFFFF - h), block max, one 64-bit atomicMax
+//   ransac_final_* re-derive F (fp64) and the inlier mask of ONE hypothesis id — every rank of a
+//                  multi-GPU run does this for the all-reduced winner, so no model is broadcast.
+//
+// Every operation below is written in the order docs/SPEC.md fixes (explicit fma, unfused
+// elsewhere; the TU is built with -ffp-contract=off) so that the CPU restatement reproduces the
+// same bits.
+#include "pm_common.hpp"
+
+namespace {
+
+constexpr int MODEL_STRIDE = 12;   // 9 x fp32 F, valid flag, 2 pad
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// SPEC S6: 8 distinct indices in [0, n) as a pure function of (seed, h, n).
+__device__ __forceinline__ void sample8(uint64_t seed, uint64_t h, int n, int (&idx)[8])
+{
+    const uint64_t stream = mix64(seed ^ 0x9E3779B97F4A7C15ULL) ^ mix64(h + 0xD1B54A32D192ED03ULL);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) idx[s] = -1;
+    int cnt = 0;
+    for (uint64_t d = 0; d < 64 && cnt < 8; ++d) {
+        const uint64_t r = mix64(stream + (d + 1) * 0x9E3779B97F4A7C15ULL);
+        const int c = static_cast<int>(((r >> 32) * static_cast<uint64_t>(static_cast<uint32_t>(n))) >> 32);
+        bool dup = false;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) dup |= (s < cnt) && (idx[s] == c);
+        if (!dup) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                if (s == cnt) idx[s] = c;
+            ++cnt;
+        }
+    }
+    for (int c = 0; cnt < 8; ++c) {
+        bool dup = false;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) dup |= (s < cnt) && (idx[s] == c);
+        if (!dup) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                if (s == cnt) idx[s] = c;
+            ++cnt;
+        }
+    }
+}
+
+// SPEC S7, Hartley normalisation of 8 points: centroid to the origin, mean distance sqrt(2).
+__device__ __forceinline__ bool hartley8(const double (&px)[8], const double (&py)[8], double (&nx)[8],
+                                         double (&ny)[8], double& s, double& tx, double& ty)
+{
+    double cx = px[0], cy = py[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) { cx = cx + px[i]; cy = cy + py[i]; }
+    cx = cx * 0.125; cy = cy * 0.125;
+    double md = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const double dx = px[i] - cx, dy = py[i] - cy;
+        md = md + sqrt(fma(dx, dx, dy * dy));
+    }
+    md = md * 0.125;
+    if (!(md > 0.0) || !(md < __builtin_inf())) return false;
+    s = 1.4142135623730951 / md;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { nx[i] = (px[i] - cx) * s; ny[i] = (py[i] - cy) * s; }
+    tx = -(s * cx); ty = -(s * cy);
+    return true;
+}
+
+// One Jacobi (Hestenes) rotation of columns P,Q of G (and V).  Compile-time column indices keep
+// everything in registers.
+template <int P, int Qc>
+__device__ __forceinline__ void jacobi_pair(double (&G)[3][3], double (&V)[3][3])
+{
+    double al = G[0][P] * G[0][P]; al = fma(G[1][P], G[1][P], al); al = fma(G[2][P], G[2][P], al);
+    double be = G[0][Qc] * G[0][Qc]; be = fma(G[1][Qc], G[1][Qc], be); be = fma(G[2][Qc], G[2][Qc], be);
+    double ga = G[0][P] * G[0][Qc]; ga = fma(G[1][P], G[1][Qc], ga); ga = fma(G[2][P], G[2][Qc], ga);
+    if (ga == 0.0 || ga != ga) return;
+    const double zeta = (be - al) / (2.0 * ga);
+    const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(fma(zeta, zeta, 1.0)));
+    const double c = 1.0 / sqrt(fma(t, t, 1.0));
+    const double s = c * t;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double gp = G[i][P], gq = G[i][Qc];
+        G[i][P] = fma(c, gp, -(s * gq));
+        G[i][Qc] = fma(s, gp, c * gq);
+        const double vp = V[i][P], vq = V[i][Qc];
+        V[i][P] = fma(c, vp, -(s * vq));
+        V[i][Qc] = fma(s, vp, c * vq);
+    }
+}
+
+// SPEC S7: normalised 8-point solve.  Returns false for a degenerate sample (F is then 0).
+__device__ __forceinline__ bool solve8(const double (&x1)[8], const double (&y1)[8], const double (&x2)[8],
+                                    const double (&y2)[8], double (&F)[9])
+{
+#pragma unroll
+    for (int i = 0; i < 9; ++i) F[i] = 0.0;
+    double ax[8], ay[8], bx[8], by[8], s1, t1x, t1y, s2, t2x, t2y;
+    if (!hartley8(x1, y1, ax, ay, s1, t1x, t1y)) return false;
+    if (!hartley8(x2, y2, bx, by, s2, t2x, t2y)) return false;
+
+    // B = A^T (9 x 8): column c is the epipolar constraint row of correspondence c
+    double B[9][8], beta[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        B[0][c] = bx[c] * ax[c]; B[1][c] = bx[c] * ay[c]; B[2][c] = bx[c];
+        B[3][c] = by[c] * ax[c]; B[4][c] = by[c] * ay[c]; B[5][c] = by[c];
+        B[6][c] = ax[c];         B[7][c] = ay[c];         B[8][c] = 1.0;
+    }
+    // Householder QR of B; reflector j stays in column j (v0 on the diagonal)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        double sigma = 0.0;
+#pragma unroll
+        for (int i = j + 1; i < 9; ++i) sigma = fma(B[i][j], B[i][j], sigma);
+        const double alpha = B[j][j];
+        const double nrm = sqrt(fma(alpha, alpha, sigma));
+        if (!(nrm > 0.0)) { beta[j] = 0.0; continue; }
+        const double v0 = alpha + (alpha >= 0.0 ? nrm : -nrm);
+        const double vtv = fma(v0, v0, sigma);
+        beta[j] = 2.0 / vtv;
+        B[j][j] = v0;
+#pragma unroll
+        for (int c = j + 1; c < 8; ++c) {
+            double dot = v0 * B[j][c];
+#pragma unroll
+            for (int i = j + 1; i < 9; ++i) dot = fma(B[i][j], B[i][c], dot);
+            const double w = beta[j] * dot;
+            B[j][c] = fma(-w, v0, B[j][c]);
+#pragma unroll
+            for (int i = j + 1; i < 9; ++i) B[i][c] = fma(-w, B[i][j], B[i][c]);
+        }
+    }
+    // null vector f = H0 H1 ... H7 e8
+    double f[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0};
+#pragma unroll
+    for (int j = 7; j >= 0; --j) {
+        if (beta[j] == 0.0) continue;
+        double dot = B[j][j] * f[j];
+#pragma unroll
+        for (int i = j + 1; i < 9; ++i) dot = fma(B[i][j], f[i], dot);
+        const double w = beta[j] * dot;
+        f[j] = fma(-w, B[j][j], f[j]);
+#pragma unroll
+        for (int i = j + 1; i < 9; ++i) f[i] = fma(-w, B[i][j], f[i]);
+    }
+    // rank 2: one-sided Jacobi on the columns of G, six fixed sweeps, then drop the smallest column
+    double G[3][3], V[3][3] = {{1.0, 0.0, 0.0}, {0.0, 1.0, 0.0}, {0.0, 0.0, 1.0}};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) G[i][j] = f[3 * i + j];
+    for (int sweep = 0; sweep < 6; ++sweep) {
+        jacobi_pair<0, 1>(G, V);
+        jacobi_pair<0, 2>(G, V);
+        jacobi_pair<1, 2>(G, V);
+    }
+    double cn[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        double a = G[0][p] * G[0][p]; a = fma(G[1][p], G[1][p], a); a = fma(G[2][p], G[2][p], a);
+        cn[p] = a;
+    }
+    int m = 0;
+    double cm = cn[0];
+    if (cn[1] < cm) { m = 1; cm = cn[1]; }
+    if (cn[2] < cm) { m = 2; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            if (p == m) G[i][p] = 0.0;
+    double Fn[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double a = G[i][0] * V[j][0]; a = fma(G[i][1], V[j][1], a); a = fma(G[i][2], V[j][2], a);
+            Fn[i][j] = a;
+        }
+    // denormalise: F = T2^T Fn T1
+    double M[3][3], Fo[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        M[i][0] = Fn[i][0] * s1;
+        M[i][1] = Fn[i][1] * s1;
+        M[i][2] = fma(Fn[i][0], t1x, fma(Fn[i][1], t1y, Fn[i][2]));
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        Fo[j] = s2 * M[0][j];
+        Fo[3 + j] = s2 * M[1][j];
+        Fo[6 + j] = fma(t2x, M[0][j], fma(t2y, M[1][j], M[2][j]));
+    }
+    double ss = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) ss = fma(Fo[i], Fo[i], ss);
+    const double nrm = sqrt(ss);
+    if (!(nrm > 0.0) || !(nrm < __builtin_inf())) return false;
+    double inv = 1.0 / nrm;
+    if (Fo[8] < 0.0) inv = -inv;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) F[i] = Fo[i] * inv;
+    return true;
+}
+
+__device__ __forceinline__ bool hyp_model(const float* __restrict__ xy1, const float* __restrict__ xy2, int n,
+                                          uint64_t seed, uint64_t h, double (&F)[9])
+{
+    int idx[8];
+    sample8(seed, h, n, idx);
+    double x1[8], y1[8], x2[8], y2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float2 a = *reinterpret_cast<const float2*>(xy1 + 2 * static_cast<size_t>(idx[i]));
+        const float2 b = *reinterpret_cast<const float2*>(xy2 + 2 * static_cast<size_t>(idx[i]));
+        x1[i] = static_cast<double>(a.x); y1[i] = static_cast<double>(a.y);
+        x2[i] = static_cast<double>(b.x); y2[i] = static_cast<double>(b.y);
+    }
+    return solve8(x1, y1, x2, y2, F);
+}
+
+// SPEC S8: fp32 inlier test of one correspondence against one model.
+template <int KIND>
+__device__ __forceinline__ bool inlier32(const float (&f)[9], float x, float y, float xp, float yp, float thr2)
+{
+    const float a = fmaf(f[0], x, fmaf(f[1], y, f[2]));
+    const float b = fmaf(f[3], x, fmaf(f[4], y, f[5]));
+    const float c = fmaf(f[6], x, fmaf(f[7], y, f[8]));
+    const float num = fmaf(xp, a, fmaf(yp, b, c));
+    const float at = fmaf(f[0], xp, fmaf(f[3], yp, f[6]));
+    const float bt = fmaf(f[1], xp, fmaf(f[4], yp, f[7]));
+    const float n2 = num * num;
+    if (KIND == PM_ERR_SAMPSON) {
+        const float den = fmaf(a, a, fmaf(b, b, fmaf(at, at, bt * bt)));
+        return n2 <= thr2 * den;
+    } else {
+        const float d2 = fmaf(a, a, b * b);
+        const float d1 = fmaf(at, at, bt * bt);
+        return (n2 <= thr2 * d2) && (n2 <= thr2 * d1);
+    }
+}
+
+__global__ __launch_bounds__(64) void ransac_solve(const float* __restrict__ xy1, const float* __restrict__ xy2,
+                                                   int n, uint64_t seed, int64_t hyp_begin, int nh,
+                                                   float* __restrict__ models)
+{
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= nh) return;
+    double F[9];
+    const bool ok = hyp_model(xy1, xy2, n, seed, static_cast<uint64_t>(hyp_begin + t), F);
+    float* m = models + static_cast<size_t>(t) * MODEL_STRIDE;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) m[i] = static_cast<float>(F[i]);
+    m[9] = ok ? 1.f : 0.f;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void ransac_score(const float* __restrict__ xy1, const float* __restrict__ xy2,
+                                                    int n, int chunk_len, const float* __restrict__ models, int nh,
+                                                    float thr2, int* __restrict__ counts)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int tl = t < nh ? t : nh - 1;
+    float f[9];
+    const float* m = models + static_cast<size_t>(tl) * MODEL_STRIDE;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) f[i] = m[i];
+    const int i0 = blockIdx.y * chunk_len;
+    int i1 = i0 + chunk_len;
+    if (i1 > n) i1 = n;
+    int cnt = 0;
+    for (int i = i0; i < i1; ++i) {
+        const float2 p = *reinterpret_cast<const float2*>(xy1 + 2 * static_cast<size_t>(i));   // wave-uniform
+        const float2 pp = *reinterpret_cast<const float2*>(xy2 + 2 * static_cast<size_t>(i));
+        cnt += inlier32<KIND>(f, p.x, p.y, pp.x, pp.y, thr2) ? 1 : 0;
+    }
+    if (t < nh && cnt) atomicAdd(&counts[t], cnt);
+}
+
+__global__ __launch_bounds__(256) void ransac_select(const float* __restrict__ models, const int* __restrict__ counts,
+                                                     int nh, int64_t hyp_begin, unsigned long long* __restrict__ best)
+{
+    __shared__ unsigned long long wbest[4];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    unsigned long long key = 0ull;
+    if (t < nh && models[static_cast<size_t>(t) * MODEL_STRIDE + 9] != 0.f) {
+        const uint32_t h = static_cast<uint32_t>(hyp_begin + t);
+        key = (static_cast<unsigned long long>(static_cast<uint32_t>(counts[t])) << 32) |
+              static_cast<unsigned long long>(0xFFFFFFFFu - h);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long w = __shfl_xor(key, o, 64);
+        key = w > key ? w : key;
+    }
+    if ((threadIdx.x & 63) == 0) wbest[threadIdx.x >> 6] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long k = wbest[0];
+        for (int w = 1; w < 4; ++w) k = wbest[w] > k ? wbest[w] : k;
+        if (k) atomicMax(best, k);
+    }
+}
+
+// result block in device memory: 9 doubles F, then int32 valid, int32 n_inliers
+struct FinalOut {
+    double F[9];
+    int valid;
+    int n_inliers;
+    float F32[9];
+    int pad;
+};
+
+__global__ __launch_bounds__(64) void ransac_final_solve(const float* __restrict__ xy1, const float* __restrict__ xy2,
+                                                         int n, uint64_t seed, const unsigned long long* __restrict__ key,
+                                                         FinalOut* __restrict__ fo)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const unsigned long long k = *key;
+    double F[9];
+    bool ok = false;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) F[i] = 0.0;
+    if (k != 0ull) {
+        const uint32_t h = 0xFFFFFFFFu - static_cast<uint32_t>(k);
+        ok = hyp_model(xy1, xy2, n, seed, static_cast<uint64_t>(h), F);
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { fo->F[i] = ok ? F[i] : 0.0; fo->F32[i] = ok ? static_cast<float>(F[i]) : 0.f; }
+    fo->valid = ok ? 1 : 0;
+    fo->n_inliers = 0;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void ransac_final_mask(const float* __restrict__ xy1, const float* __restrict__ xy2,
+                                                         int n, float thr2, FinalOut* __restrict__ fo,
+                                                         uint8_t* __restrict__ mask)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float f[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) f[j] = fo->F32[j];
+    bool in = false;
+    if (i < n && fo->valid) {
+        const float2 p = *reinterpret_cast<const float2*>(xy1 + 2 * static_cast<size_t>(i));
+        const float2 pp = *reinterpret_cast<const float2*>(xy2 + 2 * static_cast<size_t>(i));
+        in = inlier32<KIND>(f, p.x, p.y, pp.x, pp.y, thr2);
+    }
+    if (i < n) mask[i] = in ? 1 : 0;
+    const unsigned long long b = __ballot(in);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&fo->n_inliers, __popcll(b));
+}
+
+int check_params(const pm_ransac_params* p)
+{
+    PM_REQUIRE(p != nullptr, PM_E_INVALID, "params is null");
+    PM_REQUIRE(p->hyp_begin >= 0 && p->hyp_end >= p->hyp_begin && p->hyp_end <= 0x100000000LL, PM_E_INVALID,
+               "hypothesis ids must satisfy 0 <= begin <= end <= 2^32");
+    PM_REQUIRE(p->hyp_end - p->hyp_begin <= 0x7FFFFFFFLL / MODEL_STRIDE, PM_E_INVALID, "hypothesis shard too large");
+    PM_REQUIRE(p->error_kind == PM_ERR_SAMPSON || p->error_kind == PM_ERR_SYM_EPIPOLAR, PM_E_INVALID,
+               "unknown error_kind");
+    return PM_OK;
+}
+
+// score the shard; arena must already hold room.  d_key is zeroed here.
+int score_shard(pm_ctx* ctx, const float* dxy1, const float* dxy2, int n, const pm_ransac_params* p,
+                unsigned long long* d_key, char* scratch)
+{
+    const int nh = static_cast<int>(p->hyp_end - p->hyp_begin);
+    PM_HIP_CHECK(hipMemsetAsync(d_key, 0, sizeof(unsigned long long), ctx->stream));
+    if (nh == 0) return PM_OK;
+    float* models = reinterpret_cast<float*>(scratch);
+    int* counts = reinterpret_cast<int*>(scratch + pm::align_up(sizeof(float) * MODEL_STRIDE * nh, 256));
+    PM_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(int) * nh, ctx->stream));
+    {
+        pm::ScopedKernelTime t(ctx, "ransac_solve");
+        hipLaunchKernelGGL(ransac_solve, dim3((nh + 63) / 64), dim3(64), 0, ctx->stream, dxy1, dxy2, n, p->seed,
+                           p->hyp_begin, nh, models);
+        PM_HIP_CHECK(hipGetLastError());
+    }
+    const int hb = (nh + 255) / 256;
+    int chunks = (8 * ctx->n_cu + hb - 1) / hb;
+    const int max_chunks = (n + 15) / 16;
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks < 1) chunks = 1;
+    if (chunks > 65535) chunks = 65535;
+    const int chunk_len = (n + chunks - 1) / chunks;
+    chunks = (n + chunk_len - 1) / chunk_len;
+    const float thr2 = p->thresh_px * p->thresh_px;
+    {
+        pm::ScopedKernelTime t(ctx, "ransac_score");
+        if (p->error_kind == PM_ERR_SAMPSON)
+            hipLaunchKernelGGL(ransac_score<PM_ERR_SAMPSON>, dim3(hb, chunks), dim3(256), 0, ctx->stream, dxy1, dxy2, n,
+                               chunk_len, models, nh, thr2, counts);
+        else
+            hipLaunchKernelGGL(ransac_score<PM_ERR_SYM_EPIPOLAR>, dim3(hb, chunks), dim3(256), 0, ctx->stream, dxy1,
+                               dxy2, n, chunk_len, models, nh, thr2, counts);
+        PM_HIP_CHECK(hipGetLastError());
+    }
+    {
+        pm::ScopedKernelTime t(ctx, "ransac_select");
+        hipLaunchKernelGGL(ransac_select, dim3(hb), dim3(256), 0, ctx->stream, models, counts, nh, p->hyp_begin, d_key);
+        PM_HIP_CHECK(hipGetLastError());
+    }
+    return PM_OK;
+}
+
+size_t shard_scratch_bytes(const pm_ransac_params* p)
+{
+    const size_t nh = static_cast<size_t>(p->hyp_end - p->hyp_begin);
+    return pm::align_up(sizeof(float) * MODEL_STRIDE * nh, 256) + pm::align_up(sizeof(int) * nh, 256) + 256;
+}
+
+int finalize(pm_ctx* ctx, const float* dxy1, const float* dxy2, int n, const pm_ransac_params* p,
+             const unsigned long long* d_key, FinalOut* d_fo, uint8_t* d_mask)
+{
+    pm::ScopedKernelTime t(ctx, "ransac_final");
+    hipLaunchKernelGGL(ransac_final_solve, dim3(1), dim3(64), 0, ctx->stream, dxy1, dxy2, n, p->seed, d_key, d_fo);
+    const float thr2 = p->thresh_px * p->thresh_px;
+    if (p->error_kind == PM_ERR_SAMPSON)
+        hipLaunchKernelGGL(ransac_final_mask<PM_ERR_SAMPSON>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, dxy1,
+                           dxy2, n, thr2, d_fo, d_mask);
+    else
+        hipLaunchKernelGGL(ransac_final_mask<PM_ERR_SYM_EPIPOLAR>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream,
+                           dxy1, dxy2, n, thr2, d_fo, d_mask);
+    PM_HIP_CHECK(hipGetLastError());
+    return PM_OK;
+}
+
+// Shared host-pointer driver: score (when hyp < 0) or take the given hypothesis, then finalise.
+int host_run(pm_ctx* ctx, const float* xy1, const float* xy2, int n, const pm_ransac_params* p, int64_t hyp,
+             double F[9], uint8_t* mask, int* n_inliers, uint64_t* best_key)
+{
+    if (F) for (int i = 0; i < 9; ++i) F[i] = 0.0;
+    if (mask && n > 0) memset(mask, 0, static_cast<size_t>(n));
+    if (n_inliers) *n_inliers = 0;
+    if (best_key) *best_key = 0;
+    PM_REQUIRE(ctx != nullptr, PM_E_INVALID, "ctx is null");
+    int rc = check_params(p);
+    if (rc != PM_OK) return rc;
+    PM_REQUIRE(n >= 0 && (n == 0 || (xy1 && xy2)), PM_E_INVALID, "bad point arrays");
+    if (n < 8) { pm::set_error("need at least 8 correspondences, got %d", n); return PM_E_TOO_FEW; }
+    PM_REQUIRE(hyp < 0x100000000LL, PM_E_INVALID, "hypothesis id must be < 2^32");
+    PM_HIP_CHECK(hipSetDevice(ctx->device));
+
+    const size_t xyb = sizeof(float) * 2 * static_cast<size_t>(n);
+    const size_t need = 2 * pm::align_up(xyb, 256) + pm::align_up(static_cast<size_t>(n), 256) + 512 +
+                        shard_scratch_bytes(p) + 1024;
+    rc = pm::arena_reserve(ctx, need);
+    if (rc != PM_OK) return rc;
+    pm::arena_reset(ctx);
+    float* dxy1 = static_cast<float*>(pm::arena_take(ctx, xyb));
+    float* dxy2 = static_cast<float*>(pm::arena_take(ctx, xyb));
+    uint8_t* dmask = static_cast<uint8_t*>(pm::arena_take(ctx, static_cast<size_t>(n)));
+    unsigned long long* dkey = static_cast<unsigned long long*>(pm::arena_take(ctx, 8));
+    FinalOut* dfo = static_cast<FinalOut*>(pm::arena_take(ctx, sizeof(FinalOut)));
+    char* scratch = static_cast<char*>(pm::arena_take(ctx, shard_scratch_bytes(p)));
+    PM_REQUIRE(dxy1 && dxy2 && dmask && dkey && dfo && scratch, PM_E_NOMEM, "scratch arena too small");
+    rc = pm::pinned_reserve(ctx, sizeof(FinalOut) + 8 + static_cast<size_t>(n));
+    if (rc != PM_OK) return rc;
+
+    PM_HIP_CHECK(hipMemcpyAsync(dxy1, xy1, xyb, hipMemcpyHostToDevice, ctx->stream));
+    PM_HIP_CHECK(hipMemcpyAsync(dxy2, xy2, xyb, hipMemcpyHostToDevice, ctx->stream));
+    if (hyp < 0) {
+        rc = score_shard(ctx, dxy1, dxy2, n, p, dkey, scratch);
+        if (rc != PM_OK) return rc;
+    } else {
+        const unsigned long long k = pm_ransac_key(0u, static_cast<uint32_t>(hyp)) | (1ull << 32);  // non-zero
+        unsigned long long* hk = static_cast<unsigned long long*>(ctx->pinned);
+        *hk = k;
+        PM_HIP_CHECK(hipMemcpyAsync(dkey, hk, 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    rc = finalize(ctx, dxy1, dxy2, n, p, dkey, dfo, dmask);
+    if (rc != PM_OK) return rc;
+    char* hp = static_cast<char*>(ctx->pinned);
+    FinalOut* hfo = reinterpret_cast<FinalOut*>(hp + 8);
+    uint8_t* hmask = reinterpret_cast<uint8_t*>(hp + 8 + sizeof(FinalOut));
+    unsigned long long* hkey = reinterpret_cast<unsigned long long*>(hp);
+    PM_HIP_CHECK(hipMemcpyAsync(hkey, dkey, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PM_HIP_CHECK(hipMemcpyAsync(hfo, dfo, sizeof(FinalOut), hipMemcpyDeviceToHost, ctx->stream));
+    PM_HIP_CHECK(hipMemcpyAsync(hmask, dmask, static_cast<size_t>(n), hipMemcpyDeviceToHost, ctx->stream));
+    PM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (best_key && hyp < 0) *best_key = *hkey;
+    if (!hfo->valid) {
+        pm::set_error("no valid model (all hypotheses degenerate)");
+        return PM_E_NO_MODEL;
+    }
+    if (F) memcpy(F, hfo->F, sizeof(double) * 9);
+    if (mask) memcpy(mask, hmask, static_cast<size_t>(n));
+    if (n_inliers) *n_inliers = hfo->n_inliers;
+    return PM_OK;
+}
+
+}  // namespace
+
+extern "C" int pm_ransac_fundamental(pm_ctx* ctx, const float* xy1, const float* xy2, int n,
+                                     const pm_ransac_params* p, double F[9], uint8_t* mask, int* n_inliers,
+                                     uint64_t* best_key)
+{
+    return host_run(ctx, xy1, xy2, n, p, -1, F, mask, n_inliers, best_key);
+}
+
+extern "C" int pm_ransac_model_from_hyp(pm_ctx* ctx, const float* xy1, const float* xy2, int n,
+                                        const pm_ransac_params* p, int64_t hyp, double F[9], uint8_t* mask,
+                                        int* n_inliers)
+{
+    if (hyp < 0) { pm::set_error("hyp must be >= 0"); return PM_E_INVALID; }
+    pm_ransac_params q;
+    if (p) { q = *p; q.hyp_begin = 0; q.hyp_end = 0; }
+    return host_run(ctx, xy1, xy2, n, p ? &q : nullptr, hyp, F, mask, n_inliers, nullptr);
+}
+
+extern "C" int pm_ransac_score_dev(pm_ctx* ctx, const float* d_xy1, const float* d_xy2, int n,
+                                   const pm_ransac_params* p, uint64_t* d_best_key)
+{
+    PM_REQUIRE(ctx != nullptr && d_best_key != nullptr, PM_E_INVALID, "null argument");
+    int rc = check_params(p);
+    if (rc != PM_OK) return rc;
+    PM_REQUIRE(n >= 0 && (n == 0 || (d_xy1 && d_xy2)), PM_E_INVALID, "bad point arrays");
+    if (n < 8) { pm::set_error("need at least 8 correspondences, got %d", n); return PM_E_TOO_FEW; }
+    PM_HIP_CHECK(hipSetDevice(ctx->device));
+    rc = pm::arena_reserve(ctx, shard_scratch_bytes(p) + 1024);
+    if (rc != PM_OK) return rc;
+    pm::arena_reset(ctx);
+    char* scratch = static_cast<char*>(pm::arena_take(ctx, shard_scratch_bytes(p)));
+    PM_REQUIRE(scratch != nullptr, PM_E_NOMEM, "scratch arena too small");
+    return score_shard(ctx, d_xy1, d_xy2, n, p, reinterpret_cast<unsigned long long*>(d_best_key), scratch);
+}

@@ -1,0 +1,138 @@
+"""GPU parity: pm_bf_knn_l2_f32 (MFMA coarse pass + canonical refinement, and the exact kernel)
+against the CPU oracle — bit-exact trainIdx and distance bits (docs/SPEC.md S1/S3).
+Slot in the reference: matcher.match(...) at main.cpp:46 with the BF-L2 matcher of main.cpp:43."""
+import numpy as np
+import pytest
+
+import points_matching_amd as pm
+from points_matching_amd import synth
+from points_matching_amd.api import PM_KNN_FORCE_EXACT
+from util import assert_matches_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("gen", ["sift", "surf"])
+@pytest.mark.parametrize("k", [1, 2])
+def test_knn_small_both_paths(ctx, oracle, gen, k):
+    q, t, truth = (synth.sift_like if gen == "sift" else synth.surf_like)(256, 256, 128, seed=11)
+    want = oracle.bf_knn_l2(q, t, k)
+    assert_matches_equal(ctx.bf_knn_l2(q, t, k), want, "fast")
+    assert_matches_equal(ctx.bf_knn_l2(q, t, k, PM_KNN_FORCE_EXACT), want, "exact")
+    planted = truth >= 0
+    assert (want["trainIdx"][planted, 0] == truth[planted]).all()
+
+
+@pytest.mark.parametrize("nq,nt,dim", [(100, 77, 128), (1, 300, 128), (300, 1, 128), (65, 64, 64),
+                                       (129, 130, 32), (33, 200, 96), (50, 70, 12), (17, 5, 8)])
+def test_knn_ragged_shapes(ctx, oracle, nq, nt, dim):
+    q, t, _ = synth.surf_like(nq, nt, dim, seed=nq * 1000 + nt)
+    for k in (1, 2):
+        want = oracle.bf_knn_l2(q, t, k)
+        assert_matches_equal(ctx.bf_knn_l2(q, t, k), want, "fast %s" % ((nq, nt, dim, k),))
+        assert_matches_equal(ctx.bf_knn_l2(q, t, k, PM_KNN_FORCE_EXACT), want, "exact")
+
+
+@pytest.mark.parametrize("nq,nt,dim,k", [(40, 90, 7, 2), (40, 90, 200, 1), (70, 300, 130, 3),
+                                         (64, 100, 128, 5), (30, 40, 128, 16), (10, 3, 64, 4),
+                                         (20, 200, 300, 9)])
+def test_knn_general_kernel(ctx, oracle, nq, nt, dim, k):
+    """dims that are not a multiple of 4 / above 128 and k > 2 take the exact kernel."""
+    q, t, _ = synth.surf_like(nq, nt, dim, seed=dim * 7 + k)
+    assert_matches_equal(ctx.bf_knn_l2(q, t, k), oracle.bf_knn_l2(q, t, k), str((nq, nt, dim, k)))
+
+
+def test_knn_duplicate_rows_lowest_index_wins(ctx, oracle):
+    q, t, _ = synth.sift_like(64, 256, 128, seed=3)
+    t[200] = t[10]
+    t[77] = t[10]
+    q[5] = t[10]
+    # a run of identical rows longer than the coarse candidate list forces the re-scan branch
+    t[128:140] = t[20]
+    q[6] = t[20]
+    want = oracle.bf_knn_l2(q, t, 2)
+    assert want["trainIdx"][5, 0] == 10 and want["trainIdx"][5, 1] == 77
+    assert want["trainIdx"][6, 0] == 20 and want["trainIdx"][6, 1] == 128
+    assert_matches_equal(ctx.bf_knn_l2(q, t, 2), want, "dups fast")
+    assert_matches_equal(ctx.bf_knn_l2(q, t, 2, PM_KNN_FORCE_EXACT), want, "dups exact")
+
+
+def test_knn_near_ties_general_floats(ctx, oracle):
+    """Train rows that differ from each other by a few ulps: the coarse MFMA ranking cannot
+    separate them, the canonical refinement must."""
+    rng = np.random.default_rng(5)
+    q, t, _ = synth.surf_like(128, 512, 128, seed=9)
+    for i in range(0, 128, 4):
+        base = q[i].copy()
+        for r in range(6):
+            row = base.copy()
+            row[rng.integers(0, 128, 3)] *= np.float32(1 + (r + 1) * 1.2e-7)
+            t[(i * 3 + r * 17) % 512] = row
+    want = oracle.bf_knn_l2(q, t, 2)
+    assert_matches_equal(ctx.bf_knn_l2(q, t, 2), want, "near ties")
+
+
+def test_knn_non_finite_inputs_take_the_exact_route(ctx, oracle):
+    q, t, _ = synth.surf_like(40, 100, 128, seed=21)
+    t[7, 3] = np.nan
+    t[9, 0] = np.inf
+    q[4, 1] = np.nan
+    want = oracle.bf_knn_l2(q, t, 2)
+    got = ctx.bf_knn_l2(q, t, 2)
+    # NaN payload bits are not part of the contract: compare indices, and distances where finite
+    assert (got["trainIdx"] == want["trainIdx"]).all()
+    fin = np.isfinite(want["distance"])
+    assert (got["distance"][fin].view(np.uint32) == want["distance"][fin].view(np.uint32)).all()
+    assert (np.isnan(got["distance"]) == np.isnan(want["distance"])).all()
+
+
+def test_knn_empty_and_invalid(ctx):
+    q = np.zeros((0, 128), np.float32)
+    t = np.zeros((10, 128), np.float32)
+    assert ctx.bf_knn_l2(q, t, 2).shape == (0, 2)
+    out = ctx.bf_knn_l2(np.zeros((3, 128), np.float32), np.zeros((0, 128), np.float32), 2)
+    assert (out["trainIdx"] == -1).all() and np.isinf(out["distance"]).all()
+    assert (out["queryIdx"][:, 0] == np.arange(3)).all()
+    with pytest.raises(pm.PmError):
+        ctx.bf_knn_l2(t, t, 0)
+    with pytest.raises(pm.PmError):
+        ctx.bf_knn_l2(t, t, 17)
+
+
+def test_knn_c2_2k_full_parity(ctx, oracle):
+    """BASELINE config C2: 2k x 2k SIFT-128, k=2 + ratio test."""
+    q, t, truth = synth.sift_like(2048, 2048, 128, seed=0xC2)
+    want = oracle.bf_knn_l2(q, t, 2, nthreads=8)
+    got = ctx.bf_knn_l2(q, t, 2)
+    assert_matches_equal(got, want, "C2 sift")
+    good = pm.api.filter_ratio(got, 0.8)
+    good_o = oracle.filter_ratio(want, 0.8)
+    assert_matches_equal(good, good_o, "C2 ratio")
+    planted = np.nonzero(truth >= 0)[0]
+    kept = set(good["queryIdx"].tolist())
+    assert len(kept & set(planted.tolist())) > 0.9 * planted.size
+    q, t, _ = synth.surf_like(2048, 2048, 128, seed=0xC2)
+    assert_matches_equal(ctx.bf_knn_l2(q, t, 2), oracle.bf_knn_l2(q, t, 2, nthreads=8), "C2 surf")
+
+
+def test_knn_c3_8k_full_size(ctx, oracle):
+    """BASELINE config C3 matcher: 8k x 8k x 128.  Full oracle parity (the vectorised oracle
+    needs a few seconds) plus size-independent properties."""
+    q, t, truth = synth.sift_like(8192, 8192, 128, seed=0xC3)
+    got = ctx.bf_knn_l2(q, t, 2)
+    want = oracle.bf_knn_l2(q, t, 2, nthreads=8)
+    assert_matches_equal(got, want, "C3")
+    # properties: rows sorted, indices in range and distinct, planted pairs found, and the
+    # reported distance is the canonical distance of the reported pair
+    assert (got["distance"][:, 0] <= got["distance"][:, 1]).all()
+    assert (got["trainIdx"] >= 0).all() and (got["trainIdx"] < 8192).all()
+    assert (got["trainIdx"][:, 0] != got["trainIdx"][:, 1]).all()
+    planted = truth >= 0
+    assert (got["trainIdx"][planted, 0] == truth[planted]).mean() > 0.999
+    for i in (0, 17, 4095, 8191):
+        d = np.sqrt(oracle.l2sqr(q[i], t[got["trainIdx"][i, 0]]))
+        assert np.float32(d).view(np.uint32) == got["distance"][i, 0].view(np.uint32)
+    # permuting the train rows permutes the indices
+    perm = np.random.default_rng(1).permutation(8192)
+    got_p = ctx.bf_knn_l2(q[:512], t[perm], 1)
+    assert (perm[got_p["trainIdx"][:, 0]] == got["trainIdx"][:512, 0]).mean() > 0.999

@@ -1,0 +1,101 @@
+"""GPU parity: pm_ransac_fundamental vs the CPU oracle — best key (inlier count + hypothesis id),
+inlier mask and F all bit-exact (docs/SPEC.md S6-S10).  Slot in the reference:
+cv::findFundamentalMat at main.cpp:95-98."""
+import numpy as np
+import pytest
+
+import points_matching_amd as pm
+from points_matching_amd import synth
+from points_matching_amd.api import (PM_E_NO_MODEL, PM_E_TOO_FEW, PM_ERR_SAMPSON, PM_ERR_SYM_EPIPOLAR,
+                                     PM_OK, ransac_key_hyp, ransac_key_inliers)
+
+pytestmark = pytest.mark.gpu
+
+# F is computed with identical fp64 operation sequences on both sides; the stated tolerance is
+# 0 ulp (bit-exact).  Should a future compiler change break that, 1e-12 relative is the fallback
+# tolerance docs/SPEC.md allows for F while mask/key stay exact.
+F_TOL = 0.0
+
+
+def _same(got, want, what):
+    rc_g, F_g, mask_g, n_g, key_g = got
+    rc_w, F_w, mask_w, n_w, key_w = want
+    assert rc_g == rc_w, what
+    assert key_g == key_w, (what, ransac_key_hyp(key_g), ransac_key_inliers(key_g),
+                            ransac_key_hyp(key_w), ransac_key_inliers(key_w))
+    assert n_g == n_w, what
+    assert (mask_g == mask_w).all(), what
+    assert np.abs(F_g - F_w).max() <= F_TOL, (what, F_g, F_w)
+    assert (F_g.view(np.uint64) == F_w.view(np.uint64)).all(), what
+
+
+@pytest.mark.parametrize("n,iters,out_frac,noise", [(512, 500, 0.0, 0.0), (512, 1000, 0.3, 0.5),
+                                                    (100, 300, 0.5, 1.0), (8, 50, 0.0, 0.2),
+                                                    (9, 64, 0.2, 0.5), (2300, 2000, 0.3, 0.5)])
+@pytest.mark.parametrize("kind", [PM_ERR_SAMPSON, PM_ERR_SYM_EPIPOLAR])
+def test_ransac_parity(ctx, oracle, n, iters, out_frac, noise, kind):
+    x1, x2, Fgt, inl = synth.two_view(n, seed=n + iters, outlier_frac=out_frac, noise_px=noise)
+    got = ctx.ransac_fundamental(x1, x2, iters, 1.0, 0x5EED, kind)
+    want = oracle.ransac_fundamental(x1, x2, iters, 1.0, 0x5EED, kind, nthreads=8)
+    _same(got, want, str((n, iters, kind)))
+    if noise == 0.0 and out_frac == 0.0:
+        assert got[3] == n                       # every correspondence is an inlier
+        assert min(np.abs(got[1] - Fgt).max(), np.abs(got[1] + Fgt).max()) < 1e-5
+
+
+def test_ransac_every_hypothesis_model_matches(ctx, oracle):
+    """model_from_hyp for many ids: sampler + solver + scoring parity per hypothesis."""
+    x1, x2, _, _ = synth.two_view(700, seed=77)
+    for h in list(range(0, 40)) + [12345, 2 ** 31 + 5, 2 ** 32 - 1]:
+        rc_g, F_g, mask_g, n_g = ctx.ransac_model_from_hyp(x1, x2, h, 1.5, 99)
+        rc_w, F_w, mask_w, n_w = oracle.ransac_model_from_hyp(x1, x2, h, 1.5, 99)
+        assert rc_g == rc_w and n_g == n_w, h
+        assert (F_g.view(np.uint64) == F_w.view(np.uint64)).all(), (h, F_g, F_w)
+        assert (mask_g == mask_w).all(), h
+
+
+def test_ransac_shards_reduce_to_the_unsharded_answer(ctx, oracle):
+    """Partition independence: max over per-shard keys == the unsharded key (this is the
+    8-byte all-reduce of the multi-GPU path), and every shard recomputes the same model."""
+    x1, x2, _, _ = synth.two_view(1500, seed=5)
+    H = 4000
+    full = ctx.ransac_fundamental(x1, x2, H, 1.0, 7)
+    keys = []
+    for g in range(8):
+        r = ctx.ransac_fundamental(x1, x2, (g + 1) * H // 8, 1.0, 7, hyp_begin=g * H // 8)
+        keys.append(r[4])
+        assert g * H // 8 <= ransac_key_hyp(r[4]) < (g + 1) * H // 8
+    assert max(keys) == full[4]
+    rc, F, mask, n = ctx.ransac_model_from_hyp(x1, x2, ransac_key_hyp(max(keys)), 1.0, 7)
+    assert rc == PM_OK and n == full[3] and (mask == full[2]).all()
+    assert (F.view(np.uint64) == full[1].view(np.uint64)).all()
+    assert full[4] == oracle.ransac_fundamental(x1, x2, H, 1.0, 7, nthreads=8)[4]
+
+
+def test_ransac_too_few_and_degenerate(ctx, oracle):
+    x1, x2, _, _ = synth.two_view(7, seed=1)
+    rc, F, mask, n, key = ctx.ransac_fundamental(x1, x2, 10, 1.0, 1)
+    assert rc == PM_E_TOO_FEW and key == 0 and not F.any()
+    same = np.tile(np.array([[100.0, 200.0]], np.float32), (20, 1))
+    got = ctx.ransac_fundamental(same, same, 50, 1.0, 1)
+    want = oracle.ransac_fundamental(same, same, 50, 1.0, 1)
+    assert got[0] == PM_E_NO_MODEL == -3 and want[0] == -3
+    assert got[4] == 0 and not got[1].any() and not got[2].any()
+    with pytest.raises(pm.PmError):
+        ctx.ransac_fundamental(np.zeros((20, 2), np.float32), np.zeros((20, 2), np.float32), 10, 1.0, 1, kind=5)
+
+
+def test_ransac_c3_full(ctx, oracle):
+    """BASELINE config C3 robust-F stage: 10k hypotheses, ~2.3k putative matches, 30% outliers,
+    tau = 1 px Sampson, seed 0x5EED."""
+    x1, x2, Fgt, inl = synth.two_view(2300, seed=0xC3, outlier_frac=0.3, noise_px=0.5)
+    got = ctx.ransac_fundamental(x1, x2, 10000, 1.0, 0x5EED)
+    want = oracle.ransac_fundamental(x1, x2, 10000, 1.0, 0x5EED, nthreads=8)
+    _same(got, want, "C3")
+    mask = got[2].astype(bool)
+    assert (mask & ~inl).sum() < 0.05 * mask.sum()     # few outliers leak in
+    assert mask.sum() > 0.7 * inl.sum()
+    # residual report on the inliers (main.cpp:103-123) is small for the recovered F
+    r, mean_abs = pm.api.epipolar_residuals(x1[mask], x2[mask], pm.api.f_scale_f33(got[1]), transposed=0)
+    r_o, mean_o = oracle.epipolar_residuals(x1[mask], x2[mask], oracle.f_scale_f33(want[1]), 0)
+    assert (r == r_o).all() and mean_abs == mean_o
