@@ -1,0 +1,250 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the hot path on MI355X (contract: see task brief).
+
+Workload (BASELINE.json configs[2], "C3"): 8k x 8k SIFT-128 float descriptors, brute-force L2
+2-NN + ratio test (0.8), then 10 000-hypothesis RANSAC-F (normalised 8-point, Sampson, tau = 1 px)
+on the ~2.3k surviving matches.  It carries BOTH halves of BASELINE.json's metric
+("descriptor-pair distances/s + RANSAC hypotheses/s") and fits one GPU; configs[1] (2k x 2k) is
+launch-latency sized and is covered as a parity test instead.
+
+One step = one pass of the path over one image pair, everything resident in HBM:
+  pm_bf_knn_l2_f32_dev -> pm_filter_ratio_gather_dev -> pm_ransac_score_devn
+  -> [N>1: all-gather of survivors before RANSAC, 8-byte all-reduce(max) of the key after]
+  -> pm_ransac_model_from_key_dev (F + inlier mask of the winner)
+N GPUs (weak scaling): rank r matches its own 8k query rows against the replicated 8k train
+rows (global problem = N*8k x 8k), the survivors are all-gathered (RCCL), every rank scores its
+shard of the 10k hypothesis ids over ALL gathered correspondences, one all-reduce(max) of the
+packed (inliers, ~id) key picks the global winner, and every rank re-derives the same F + mask.
+
+`value` = descriptor-pair distances/s of the matching stage (N*M*ranks / match-stage time);
+the RANSAC half of the metric is reported next to it (`ransac.hyp_per_s`, with N_m).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense f32-input MFMA = f32 vector peak
+PEAK_F32_VALU_TFLOPS = 157.3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--nq", type=int, default=8192)
+    ap.add_argument("--nt", type=int, default=8192)
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--hyps", type=int, default=10000)
+    ap.add_argument("--kind", default="sift", choices=["sift", "surf"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import points_matching_amd as pm
+    from points_matching_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
+
+    nq, nt, dim, H, K = args.nq, args.nt, args.dim, args.hyps, 2
+    ratio, thresh, seed = 0.8, 1.0, 0x5EED
+    w = synth.pair_workload(nq, nt, dim, seed=0xC3, rank=rank, kind=args.kind)
+
+    ctx = pm.Context(local_rank)
+    stream = torch.cuda.Stream(device=dev)      # a real (non-null) stream shared by torch and the library
+    torch.cuda.set_stream(stream)
+    ctx.set_stream(stream.cuda_stream)
+
+    d_q = torch.from_numpy(w["q"]).to(dev)
+    d_t = torch.from_numpy(w["t"]).to(dev)
+    d_kp1 = torch.from_numpy(w["kp1"]).to(dev)
+    d_kp2 = torch.from_numpy(w["kp2"]).to(dev)
+    d_knn = torch.empty((nq, K, 4), dtype=torch.int32, device=dev)
+    d_good = torch.empty((nq, 4), dtype=torch.int32, device=dev)
+    d_xy1 = torch.zeros((nq, 2), dtype=torch.float32, device=dev)
+    d_xy2 = torch.zeros((nq, 2), dtype=torch.float32, device=dev)
+    d_n = torch.zeros(1, dtype=torch.int32, device=dev)
+    d_key = torch.zeros(1, dtype=torch.int64, device=dev)
+    n_all_max = nq * world
+    d_F = torch.zeros(9, dtype=torch.float64, device=dev)
+    d_mask = torch.zeros(n_all_max, dtype=torch.uint8, device=dev)
+    d_ninl = torch.zeros(1, dtype=torch.int32, device=dev)
+    if world > 1:
+        g_xy1 = torch.zeros((world, nq, 2), dtype=torch.float32, device=dev)
+        g_xy2 = torch.zeros((world, nq, 2), dtype=torch.float32, device=dev)
+        g_n = torch.zeros(world, dtype=torch.int32, device=dev)
+        a_xy1 = torch.zeros((n_all_max, 2), dtype=torch.float32, device=dev)
+        a_xy2 = torch.zeros((n_all_max, 2), dtype=torch.float32, device=dev)
+        a_n = torch.zeros(1, dtype=torch.int32, device=dev)
+    hb = rank * H // world
+    he = (rank + 1) * H // world
+
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+
+    def step(e=None):
+        if e:
+            e[0].record(stream)
+        ctx.bf_knn_l2_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, K, d_knn.data_ptr())
+        ctx.filter_ratio_gather_dev(d_knn.data_ptr(), nq, K, ratio, d_kp1.data_ptr(), d_kp2.data_ptr(),
+                                    d_good.data_ptr(), d_xy1.data_ptr(), d_xy2.data_ptr(), d_n.data_ptr())
+        if e:
+            e[1].record(stream)
+        if world > 1:
+            dist.all_gather_into_tensor(g_xy1, d_xy1)
+            dist.all_gather_into_tensor(g_xy2, d_xy2)
+            dist.all_gather_into_tensor(g_n, d_n)
+            ctx.concat_points_dev(g_xy1.data_ptr(), g_xy2.data_ptr(), g_n.data_ptr(), world, nq,
+                                  a_xy1.data_ptr(), a_xy2.data_ptr(), a_n.data_ptr())
+            x1, x2, nn = a_xy1, a_xy2, a_n
+        else:
+            x1, x2, nn = d_xy1, d_xy2, d_n
+        ctx.ransac_score_devn(x1.data_ptr(), x2.data_ptr(), n_all_max, nn.data_ptr(), hb, he, thresh, seed,
+                              d_key.data_ptr())
+        if world > 1:
+            dist.all_reduce(d_key, op=dist.ReduceOp.MAX)      # the single 8-byte exchange
+        ctx.ransac_model_from_key_dev(x1.data_ptr(), x2.data_ptr(), n_all_max, nn.data_ptr(), thresh, seed,
+                                      d_key.data_ptr(), d_F.data_ptr(), d_mask.data_ptr(), d_ninl.data_ptr())
+        if e:
+            e[2].record(stream)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(ev[i])
+    fence()
+    t1 = time.perf_counter()
+    wall = t1 - t0
+    match_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    rest_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    if world > 1:
+        tt = torch.tensor([wall, match_ms, rest_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall, match_ms, rest_ms = [float(x) for x in tt.tolist()]
+    ms_per_step = wall / args.steps * 1e3
+
+    n_m = int((a_n if world > 1 else d_n).item())
+    key = int(d_key.item())
+    n_inl = int(d_ninl.item())
+
+    # ---- per-kernel durations: instrumented replay of the same K steps (hipEvents on the stream
+    # the kernels run on, recorded inside the library around each launch)
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    for _ in range(args.steps):
+        step()
+    fence()
+    kern = {}
+    for name in ("knn_l2_prep", "knn_l2_mfma", "knn_l2_refine", "filter_gather", "ransac_solve", "ransac_score",
+                 "ransac_select", "ransac_final", "concat_points"):
+        ms, cnt = ctx.timing_get(name)
+        if cnt:
+            kern[name] = round(ms * 1e3, 2)           # microseconds
+    ctx.timing_enable(False)
+    # diagnostics of the coarse/refine split (a kNN call on its own, so the arena still holds them)
+    ctx.bf_knn_l2_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, K, d_knn.data_ptr())
+    kstats = ctx.knn_stats()
+
+    # ---- parity spot check against the CPU oracle (untimed; checker only)
+    parity = "skipped"
+    if not args.no_verify and rank == 0:
+        from oracle import pm_oracle as O
+        got = d_knn.cpu().numpy().view(pm.MATCH_DTYPE).reshape(nq, K)
+        rows = np.random.default_rng(0).permutation(nq)[:256]
+        want = O.bf_knn_l2(w["q"][rows], w["t"], K, nthreads=8)
+        ok = (got["trainIdx"][rows] == want["trainIdx"]).all() and \
+             (got["distance"][rows].view(np.uint32) == want["distance"].view(np.uint32)).all()
+        xs1 = (a_xy1 if world > 1 else d_xy1)[:n_m].cpu().numpy()
+        xs2 = (a_xy2 if world > 1 else d_xy2)[:n_m].cpu().numpy()
+        rc, F_o, mask_o, ninl_o, key_o = O.ransac_fundamental(xs1, xs2, H, thresh, seed, nthreads=8)
+        ok = ok and key_o == key and ninl_o == n_inl and (mask_o == d_mask[:n_m].cpu().numpy()).all() \
+            and (F_o.reshape(9).view(np.uint64) == d_F.cpu().numpy().view(np.uint64)).all()
+        parity = "ok" if ok else "MISMATCH"
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    pairs = float(nq) * nt * world
+    value = pairs / (match_ms * 1e-3)
+    hyp_per_s = H / (rest_ms * 1e-3)
+
+    out = {
+        "metric": "descriptor-pair distances/s (BF-L2 2-NN + ratio stage); RANSAC hypotheses/s in `ransac`",
+        "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C3: %dx%d SIFT-%d f32 BF-L2 2-NN + ratio 0.8 + %d-hypothesis RANSAC-F (8-point, "
+                               "Sampson, tau=1px) per image pair; N>1: query rows and hypothesis ids sharded"
+                               % (nq, nt, dim, H), "descriptors": args.kind, "k": K},
+        "stage_ms": {"match": match_ms, "ransac_and_exchange": rest_ms},
+        "ransac": {"hyp_per_s": hyp_per_s, "hypotheses": H, "n_matches": n_m, "inliers": n_inl,
+                   "best_hyp": pm.api.ransac_key_hyp(key) if key else None},
+        "kernels_us": kern, "knn_refine": kstats, "parity": parity,
+    }
+    # roofline of the dominant kernel (algorithmic 2*D flop per descriptor pair)
+    if "knn_l2_mfma" in kern:
+        flops = 2.0 * dim * nq * nt
+        ach = flops / (kern["knn_l2_mfma"] * 1e-6) / 1e12
+        out["roofline"] = {"kernel": "knn_l2_mfma", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+                           "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                           "dtype": "f32-input MFMA (v_mfma_f32_32x32x2_f32)"}
+    if "ransac_score" in kern and n_m:
+        flops = 34.0 * n_m * (he - hb)
+        ach = flops / (kern["ransac_score"] * 1e-6) / 1e12
+        out["roofline_ransac"] = {"kernel": "ransac_score", "bound": "valu-f32", "achieved": ach,
+                                  "peak": PEAK_F32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_VALU_TFLOPS,
+                                  "flops_per_pair": 34, "n_matches": n_m, "traffic": None}
+
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import pm_oracle as O
+        sample_q = min(nq, 2048)
+        t0 = time.perf_counter()
+        m = O.bf_knn_l2(w["q"][:sample_q], w["t"], K, nthreads=1)
+        t_knn = time.perf_counter() - t0
+        good = O.filter_ratio(O.bf_knn_l2(w["q"], w["t"], K, nthreads=os.cpu_count() or 1), ratio)
+        xs1 = O.gather_points(w["kp1"], good["queryIdx"])
+        xs2 = O.gather_points(w["kp2"], good["trainIdx"])
+        t0 = time.perf_counter()
+        O.ransac_fundamental(xs1, xs2, H, thresh, seed, nthreads=1)
+        t_r = time.perf_counter() - t0
+        out["cpu_baseline"] = {
+            "value": sample_q * nt / t_knn, "unit": "pairs/s", "cores": 1, "kind": "port",
+            "sample": "oracle (CPU restatement, AVX2-vectorised by gcc, 1 thread): matcher on the first %d of %d "
+                      "query rows x %d train rows; RANSAC-F on the full %d hypotheses x %d matches"
+                      % (sample_q, nq, nt, H, good.size),
+            "ransac_hyp_per_s": H / t_r, "host_cpus": os.cpu_count(),
+        }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

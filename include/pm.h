@@ -71,6 +71,9 @@ int  pm_ctx_synchronize(pm_ctx* ctx);
 int  pm_ctx_timing_enable(pm_ctx* ctx, int enable);
 int  pm_ctx_timing_reset(pm_ctx* ctx);
 int  pm_ctx_timing_get(pm_ctx* ctx, const char* kernel, double* mean_ms, int* launches);
+/* Diagnostics of the last pm_bf_knn_l2_f32[_dev] call on this context (synchronises):
+ * queries that took the exact re-scan branch of the refinement, and the non-finite-input flag. */
+int  pm_ctx_knn_stats(pm_ctx* ctx, int* rescans, int* nonfinite);
 const char* pm_last_error(void);       /* thread-local text of the last PM_E_HIP / PM_E_* */
 const char* pm_status_string(int status);
 int  pm_version(void);                 /* major*100 + minor */
@@ -111,6 +114,19 @@ int pm_filter_midpoint(const pm_match* m, int n, double* min_out, double* max_ou
 /* Ratio test on k-NN rows (k >= 2): keep row i iff knn[i*k+1].trainIdx >= 0 and
  * knn[i*k].distance < ratio * knn[i*k+1].distance (float multiply, strict).  Emits knn[i*k]. */
 int pm_filter_ratio(const pm_match* knn, int nq, int k, float ratio, pm_match* out, int* n_out);
+/* Device-resident fusion of pm_filter_ratio + pm_match_indices + pm_gather_points (main.cpp:49-69,
+ * :77-78, :89-91) for batches that stay in HBM between the matcher and RANSAC: stable compaction
+ * in query order.  d_good: nq records; d_xy1/d_xy2: nq x 2 floats (may be NULL together with the
+ * keypoint arrays when only the match list is wanted); *d_n_good: survivor count (device int). */
+int pm_filter_ratio_gather_dev(pm_ctx* ctx, const pm_match* d_knn, int nq, int k, float ratio,
+                               const float* d_kp1_xy, const float* d_kp2_xy, pm_match* d_good,
+                               float* d_xy1, float* d_xy2, int32_t* d_n_good);
+/* Multi-GPU glue: concatenates `parts` padded blocks of `stride` points (d_counts[p] valid in
+ * block p), e.g. the all-gathered per-rank survivors of a query-row-sharded matcher, into one
+ * contiguous correspondence array in part order; *d_n_total = sum of counts. */
+int pm_concat_points_dev(pm_ctx* ctx, const float* d_xy1_parts, const float* d_xy2_parts,
+                         const int32_t* d_counts, int parts, int stride, float* d_xy1,
+                         float* d_xy2, int32_t* d_n_total);
 
 /* ---- match list + gather (main.cpp:71-79, :89-91) ------------------------------------------
  * pm_match_indices: pointIndexes1/2 of main.cpp:77-78.
@@ -151,6 +167,18 @@ int pm_ransac_fundamental(pm_ctx* ctx, const float* xy1, const float* xy2, int n
  * the shard's best key in *d_best_key (device uint64).  No model is materialised. */
 int pm_ransac_score_dev(pm_ctx* ctx, const float* d_xy1, const float* d_xy2, int n,
                         const pm_ransac_params* p, uint64_t* d_best_key);
+/* Same, with the correspondence count read on the device: n = min(*d_n, n_max).  Lets a batch
+ * flow matcher -> pm_filter_ratio_gather_dev -> RANSAC without a host round trip.  *d_n < 8
+ * leaves *d_best_key = 0. */
+int pm_ransac_score_devn(pm_ctx* ctx, const float* d_xy1, const float* d_xy2, int n_max,
+                         const int32_t* d_n, const pm_ransac_params* p, uint64_t* d_best_key);
+/* Device-resident finalisation: F (9 doubles), mask (n_max bytes, zero beyond n) and inlier
+ * count of the hypothesis encoded in *d_key (e.g. the all-reduced winner).  d_n may be NULL
+ * (then n = n_max).  A zero key / n < 8 gives F = 0, mask = 0, count 0. */
+int pm_ransac_model_from_key_dev(pm_ctx* ctx, const float* d_xy1, const float* d_xy2, int n_max,
+                                 const int32_t* d_n, const pm_ransac_params* p,
+                                 const uint64_t* d_key, double* d_F, uint8_t* d_mask,
+                                 int32_t* d_n_inliers);
 /* Re-derives F + mask of ONE hypothesis id (every rank calls this with the reduced winner:
  * no model broadcast is needed).  hyp is the id, not the key. */
 int pm_ransac_model_from_hyp(pm_ctx* ctx, const float* xy1, const float* xy2, int n,

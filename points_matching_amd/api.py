@@ -24,12 +24,15 @@ PM_OK, PM_E_INVALID, PM_E_TOO_FEW, PM_E_NO_MODEL, PM_E_HIP, PM_E_NOMEM, PM_E_UNS
 # every extern "C" symbol include/pm.h declares (tests check the library exports all of them)
 EXPORTS = [
     "pm_ctx_create", "pm_ctx_destroy", "pm_ctx_set_stream", "pm_ctx_synchronize",
-    "pm_ctx_timing_enable", "pm_ctx_timing_reset", "pm_ctx_timing_get", "pm_last_error",
+    "pm_ctx_timing_enable", "pm_ctx_timing_reset", "pm_ctx_timing_get", "pm_ctx_knn_stats",
+    "pm_last_error",
     "pm_status_string", "pm_version",
     "pm_bf_knn_l2_f32", "pm_bf_knn_l2_f32_dev", "pm_bf_knn_hamming_u8", "pm_bf_knn_hamming_u8_dev",
     "pm_filter_midpoint", "pm_filter_ratio", "pm_match_indices", "pm_gather_points",
     "pm_format_match_list",
-    "pm_ransac_fundamental", "pm_ransac_score_dev", "pm_ransac_model_from_hyp",
+    "pm_filter_ratio_gather_dev", "pm_concat_points_dev",
+    "pm_ransac_fundamental", "pm_ransac_score_dev", "pm_ransac_score_devn", "pm_ransac_model_from_hyp",
+    "pm_ransac_model_from_key_dev",
     "pm_epipolar_residuals", "pm_f_scale_f33", "pm_epilines", "pm_epiline_endpoints",
 ]
 
@@ -55,6 +58,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise PmError(PM_E_UNSUPPORTED,
                           "%s is missing: run `python -m points_matching_amd.build`" % LIB_PATH)
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 and cannot
+        # initialise after another copy (the /opt/rocm one libpm_hip.so would pull in) has taken
+        # the device.  Importing torch first makes libpm_hip.so bind to torch's runtime, which is
+        # also what lets bench.py share torch streams/tensors with the library.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = C.CDLL(LIB_PATH)
         _lib.pm_last_error.restype = C.c_char_p
         _lib.pm_status_string.restype = C.c_char_p
@@ -202,6 +213,37 @@ class Context:
         ms, n = C.c_double(), C.c_int()
         _check(lib().pm_ctx_timing_get(self._h, name.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def knn_stats(self):
+        r, nf = C.c_int(), C.c_int()
+        _check(lib().pm_ctx_knn_stats(self._h, C.byref(r), C.byref(nf)))
+        return {"rescans": r.value, "nonfinite": nf.value}
+
+    def filter_ratio_gather_dev(self, dknn_ptr, nq, k, ratio, dkp1_ptr, dkp2_ptr, dgood_ptr, dxy1_ptr,
+                                dxy2_ptr, dn_ptr):
+        _check(lib().pm_filter_ratio_gather_dev(self._h, C.c_void_p(dknn_ptr), nq, k, C.c_float(ratio),
+                                                C.c_void_p(dkp1_ptr), C.c_void_p(dkp2_ptr),
+                                                C.c_void_p(dgood_ptr), C.c_void_p(dxy1_ptr),
+                                                C.c_void_p(dxy2_ptr), C.c_void_p(dn_ptr)))
+
+    def concat_points_dev(self, dxy1_parts, dxy2_parts, dcounts, parts, stride, dxy1, dxy2, dn_total):
+        _check(lib().pm_concat_points_dev(self._h, C.c_void_p(dxy1_parts), C.c_void_p(dxy2_parts),
+                                          C.c_void_p(dcounts), parts, stride, C.c_void_p(dxy1),
+                                          C.c_void_p(dxy2), C.c_void_p(dn_total)))
+
+    def ransac_score_devn(self, dxy1_ptr, dxy2_ptr, n_max, dn_ptr, hyp_begin, hyp_end, thresh_px, seed,
+                          dkey_ptr, kind=PM_ERR_SAMPSON):
+        prm = RansacParams(hyp_begin, hyp_end, seed, thresh_px, kind)
+        _check(lib().pm_ransac_score_devn(self._h, C.c_void_p(dxy1_ptr), C.c_void_p(dxy2_ptr), n_max,
+                                          C.c_void_p(dn_ptr), C.byref(prm), C.c_void_p(dkey_ptr)))
+
+    def ransac_model_from_key_dev(self, dxy1_ptr, dxy2_ptr, n_max, dn_ptr, thresh_px, seed, dkey_ptr, dF_ptr,
+                                  dmask_ptr, dninl_ptr, kind=PM_ERR_SAMPSON):
+        prm = RansacParams(0, 0, seed, thresh_px, kind)
+        _check(lib().pm_ransac_model_from_key_dev(self._h, C.c_void_p(dxy1_ptr), C.c_void_p(dxy2_ptr), n_max,
+                                                  C.c_void_p(dn_ptr or 0), C.byref(prm), C.c_void_p(dkey_ptr),
+                                                  C.c_void_p(dF_ptr), C.c_void_p(dmask_ptr),
+                                                  C.c_void_p(dninl_ptr)))
 
     # -- matcher (main.cpp:46) -------------------------------------------------------------------
     def bf_knn_l2(self, q, t, k, flags=0):

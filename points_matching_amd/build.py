@@ -16,7 +16,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libpm_hip.so")
-SOURCES = ["pm_capi.cpp", "knn_l2.hip", "knn_hamming.hip", "ransac.hip"]
+SOURCES = ["pm_capi.cpp", "knn_l2.hip", "knn_hamming.hip", "ransac.hip", "filter_gather.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function",
@@ -64,5 +64,23 @@ def build(force=False, verbose=False, extra_flags=()):
     return LIB
 
 
+HOST_SRC = os.path.join(HERE, "host", "pm_cli.cpp")
+HOST_BIN = os.path.join(HERE, "host", "pm_cli")
+
+
+def build_host(force=False):
+    """C++ host tool (the counterpart of the reference's main()); links libpm_hip.so."""
+    if not os.path.exists(HOST_SRC):
+        return None
+    if force or _newer(HOST_SRC, HOST_BIN) or _newer(LIB, HOST_BIN):
+        cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), HOST_SRC,
+               "-o", HOST_BIN, "-L" + HERE, "-lpm_hip", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + HERE]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("host build failed:\n%s\n%s" % (" ".join(cmd), r.stderr))
+    return HOST_BIN
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))
+    print(build_host(force="--force" in sys.argv))

@@ -1,0 +1,121 @@
+// filter_gather.hip — device-resident form of the glue between the two hot kernels:
+// ratio test in the slot of main.cpp:49-69, index extraction main.cpp:77-78 and
+// KeyPoint::convert main.cpp:89-91, fused into one stable compaction so that a matched batch
+// never leaves HBM between the matcher and the RANSAC kernels.  Survivors keep query order
+// (the reference's push_back order, main.cpp:63-68).  Same predicate as pm_filter_ratio:
+// second neighbour present and d1 < ratio * d2 (float multiply, strict).
+#include "pm_common.hpp"
+
+namespace {
+
+// One workgroup of 1024 threads walks the rows in order; each pass compacts 1024 rows with a
+// ballot prefix inside the wave and a 16-entry scan across waves.
+__global__ __launch_bounds__(1024) void filter_ratio_gather(const pm_match* __restrict__ knn, int nq, int k,
+                                                            float ratio, const float* __restrict__ kp1,
+                                                            const float* __restrict__ kp2,
+                                                            pm_match* __restrict__ good, float* __restrict__ xy1,
+                                                            float* __restrict__ xy2, int* __restrict__ n_out)
+{
+    __shared__ int wave_cnt[16];
+    __shared__ int base_sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base_sh = 0;
+    __syncthreads();
+    for (int start = 0; start < nq; start += 1024) {
+        const int i = start + tid;
+        bool keep = false;
+        pm_match best;
+        best.queryIdx = 0; best.trainIdx = -1; best.imgIdx = 0; best.distance = 0.f;
+        if (i < nq) {
+            best = knn[static_cast<size_t>(i) * k];
+            const pm_match second = knn[static_cast<size_t>(i) * k + 1];
+            const float rhs = ratio * second.distance;
+            keep = best.trainIdx >= 0 && second.trainIdx >= 0 && best.distance < rhs;
+        }
+        const unsigned long long b = __ballot(keep);
+        const int before = __popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wave] = __popcll(b);
+        __syncthreads();
+        int off = base_sh;
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        if (keep) {
+            const int o = off + before;
+            good[o] = best;
+            if (kp1) {
+                xy1[2 * o] = kp1[2 * static_cast<size_t>(best.queryIdx)];
+                xy1[2 * o + 1] = kp1[2 * static_cast<size_t>(best.queryIdx) + 1];
+                xy2[2 * o] = kp2[2 * static_cast<size_t>(best.trainIdx)];
+                xy2[2 * o + 1] = kp2[2 * static_cast<size_t>(best.trainIdx) + 1];
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; ++w) tot += wave_cnt[w];
+            base_sh += tot;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *n_out = base_sh;
+}
+
+// Concatenates `parts` padded point blocks (each `stride` points, counts[p] valid) into one
+// contiguous array in part order; used after the all-gather of the query-row-sharded matcher.
+__global__ __launch_bounds__(256) void concat_points(const float* __restrict__ xy1_parts,
+                                                     const float* __restrict__ xy2_parts,
+                                                     const int* __restrict__ counts, int parts, int stride,
+                                                     float* __restrict__ xy1, float* __restrict__ xy2,
+                                                     int* __restrict__ n_out)
+{
+    const int p = blockIdx.y;
+    int off = 0, total = 0;
+    for (int r = 0; r < parts; ++r) {
+        int c = counts[r];
+        c = c < 0 ? 0 : (c > stride ? stride : c);
+        if (r < p) off += c;
+        total += c;
+    }
+    int cp = counts[p];
+    cp = cp < 0 ? 0 : (cp > stride ? stride : cp);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < cp) {
+        const size_t s = 2 * (static_cast<size_t>(p) * stride + i), d = 2 * static_cast<size_t>(off + i);
+        xy1[d] = xy1_parts[s]; xy1[d + 1] = xy1_parts[s + 1];
+        xy2[d] = xy2_parts[s]; xy2[d + 1] = xy2_parts[s + 1];
+    }
+    if (p == 0 && i == 0) *n_out = total;
+}
+
+}  // namespace
+
+extern "C" int pm_filter_ratio_gather_dev(pm_ctx* ctx, const pm_match* d_knn, int nq, int k, float ratio,
+                                          const float* d_kp1_xy, const float* d_kp2_xy, pm_match* d_good,
+                                          float* d_xy1, float* d_xy2, int32_t* d_n_good)
+{
+    PM_REQUIRE(ctx != nullptr && d_n_good != nullptr, PM_E_INVALID, "null argument");
+    PM_REQUIRE(nq >= 0 && k >= 2, PM_E_INVALID, "ratio test needs k >= 2");
+    PM_REQUIRE(nq == 0 || (d_knn && d_good), PM_E_INVALID, "null match buffers");
+    PM_REQUIRE((d_kp1_xy == nullptr) == (d_kp2_xy == nullptr), PM_E_INVALID, "give both keypoint arrays or none");
+    PM_REQUIRE(d_kp1_xy == nullptr || (d_xy1 && d_xy2), PM_E_INVALID, "null point outputs");
+    PM_HIP_CHECK(hipSetDevice(ctx->device));
+    pm::ScopedKernelTime t(ctx, "filter_gather");
+    hipLaunchKernelGGL(filter_ratio_gather, dim3(1), dim3(1024), 0, ctx->stream, d_knn, nq, k, ratio, d_kp1_xy,
+                       d_kp2_xy, d_good, d_xy1, d_xy2, d_n_good);
+    PM_HIP_CHECK(hipGetLastError());
+    return PM_OK;
+}
+
+extern "C" int pm_concat_points_dev(pm_ctx* ctx, const float* d_xy1_parts, const float* d_xy2_parts,
+                                    const int32_t* d_counts, int parts, int stride, float* d_xy1, float* d_xy2,
+                                    int32_t* d_n_total)
+{
+    PM_REQUIRE(ctx && d_xy1_parts && d_xy2_parts && d_counts && d_xy1 && d_xy2 && d_n_total, PM_E_INVALID,
+               "null argument");
+    PM_REQUIRE(parts >= 1 && parts <= 65535 && stride >= 1, PM_E_INVALID, "bad parts/stride");
+    PM_HIP_CHECK(hipSetDevice(ctx->device));
+    pm::ScopedKernelTime t(ctx, "concat_points");
+    hipLaunchKernelGGL(concat_points, dim3((stride + 255) / 256, parts), dim3(256), 0, ctx->stream, d_xy1_parts,
+                       d_xy2_parts, d_counts, parts, stride, d_xy1, d_xy2, d_n_total);
+    PM_HIP_CHECK(hipGetLastError());
+    return PM_OK;
+}

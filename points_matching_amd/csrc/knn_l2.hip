@@ -294,7 +294,7 @@ __device__ __forceinline__ void best2_insert(Best2& b, uint64_t key, float d)
 template <bool VEC4>
 __global__ __launch_bounds__(256) void knn_l2_refine(
     const float* __restrict__ Q, const float* __restrict__ T, const float* __restrict__ qnorm,
-    const unsigned* __restrict__ stats, int nq, int nt, int dim, int k, int slots,
+    unsigned* __restrict__ stats, int nq, int nt, int dim, int k, int slots,
     const float* __restrict__ cand_val, const int* __restrict__ cand_idx, float eps_coef,
     pm_match* __restrict__ out)
 {
@@ -331,6 +331,7 @@ __global__ __launch_bounds__(256) void knn_l2_refine(
             spill |= (v + na) <= thr;
         }
     const bool rescan = nonfinite || !(thr < KNN_INF) || __any(spill);
+    if (rescan && lane == 0) atomicAdd(&stats[2], 1u);
 
     Best2 b{~0ull, ~0ull, KNN_INF, KNN_INF};
     if (!rescan) {
@@ -608,7 +609,7 @@ extern "C" int pm_bf_knn_l2_f32_dev(pm_ctx* ctx, const float* dq, int nq, const 
     PM_HIP_CHECK(hipSetDevice(ctx->device));
 
     const bool fast = !(flags & PM_KNN_FORCE_EXACT) && k <= 2 && (dim % 4) == 0 && dim <= 128 && nt >= 1;
-    if (!fast) return run_exact(ctx, dq, nq, dt, nt, dim, k, dout);
+    if (!fast) { ctx->last_knn_stats = nullptr; return run_exact(ctx, dq, nq, dt, nt, dim, k, dout); }
 
     // split the train rows so that the grid fills the chip (~2 workgroups per CU)
     const int ntiles = (nt + TILE_T - 1) / TILE_T;
@@ -636,6 +637,7 @@ extern "C" int pm_bf_knn_l2_f32_dev(pm_ctx* ctx, const float* dq, int nq, const 
     PM_REQUIRE(qnorm && tnorm && stats && cval && cidx, PM_E_NOMEM, "scratch arena too small");
 
     PM_HIP_CHECK(hipMemsetAsync(stats, 0, 16, ctx->stream));
+    ctx->last_knn_stats = stats;
     {
         pm::ScopedKernelTime t(ctx, "knn_l2_prep");
         hipLaunchKernelGGL(knn_l2_prep, dim3((nq + 15) / 16), dim3(256), 0, ctx->stream, dq, nq, dim, qnorm, stats, 0);

@@ -25,6 +25,7 @@ int arena_reserve(pm_ctx* ctx, size_t bytes)
     PM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (ctx->arena) PM_HIP_CHECK(hipFree(ctx->arena));
     ctx->arena = nullptr;
+    ctx->last_knn_stats = nullptr;
     ctx->arena_cap = 0;
     size_t cap = align_up(bytes + bytes / 4, size_t(1) << 20);
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&ctx->arena), cap);
@@ -207,6 +208,19 @@ int pm_ctx_timing_get(pm_ctx* ctx, const char* kernel, double* mean_ms, int* lau
     }
     if (mean_ms) *mean_ms = ms;
     if (launches) *launches = n;
+    return PM_OK;
+}
+
+int pm_ctx_knn_stats(pm_ctx* ctx, int* rescans, int* nonfinite)
+{
+    PM_REQUIRE(ctx != nullptr, PM_E_INVALID, "ctx is null");
+    unsigned h[4] = {0, 0, 0, 0};
+    if (ctx->last_knn_stats) {
+        PM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        PM_HIP_CHECK(hipMemcpy(h, ctx->last_knn_stats, sizeof h, hipMemcpyDeviceToHost));
+    }
+    if (rescans) *rescans = static_cast<int>(h[2]);
+    if (nonfinite) *nonfinite = static_cast<int>(h[1]);
     return PM_OK;
 }
 

@@ -59,6 +59,7 @@ struct pm_ctx {
     std::map<std::string, pm::KernelTimer> timers;
     std::vector<hipEvent_t> event_pool;
     int n_cu = 256;
+    unsigned* last_knn_stats = nullptr;   // device, 4 words, inside the arena
 };
 
 namespace pm {

@@ -262,15 +262,25 @@ __device__ __forceinline__ bool inlier32(const float (&f)[9], float x, float y, 
     }
 }
 
+// n = min(*d_n, n_max) when the count lives on the device (matcher -> filter -> RANSAC batches).
+__device__ __forceinline__ int resolve_n(int n_max, const int* __restrict__ d_n)
+{
+    if (!d_n) return n_max;
+    const int v = *d_n;
+    return v < n_max ? (v < 0 ? 0 : v) : n_max;
+}
+
 __global__ __launch_bounds__(64) void ransac_solve(const float* __restrict__ xy1, const float* __restrict__ xy2,
-                                                   int n, uint64_t seed, int64_t hyp_begin, int nh,
-                                                   float* __restrict__ models)
+                                                   int n_max, const int* __restrict__ d_n, uint64_t seed,
+                                                   int64_t hyp_begin, int nh, float* __restrict__ models)
 {
     const int t = blockIdx.x * 64 + threadIdx.x;
     if (t >= nh) return;
+    const int n = resolve_n(n_max, d_n);
+    float* m = models + static_cast<size_t>(t) * MODEL_STRIDE;
+    if (n < 8) { m[9] = 0.f; return; }
     double F[9];
     const bool ok = hyp_model(xy1, xy2, n, seed, static_cast<uint64_t>(hyp_begin + t), F);
-    float* m = models + static_cast<size_t>(t) * MODEL_STRIDE;
 #pragma unroll
     for (int i = 0; i < 9; ++i) m[i] = static_cast<float>(F[i]);
     m[9] = ok ? 1.f : 0.f;
@@ -278,9 +288,11 @@ __global__ __launch_bounds__(64) void ransac_solve(const float* __restrict__ xy1
 
 template <int KIND>
 __global__ __launch_bounds__(256) void ransac_score(const float* __restrict__ xy1, const float* __restrict__ xy2,
-                                                    int n, int chunk_len, const float* __restrict__ models, int nh,
-                                                    float thr2, int* __restrict__ counts)
+                                                    int n_max, const int* __restrict__ d_n, int chunk_len,
+                                                    const float* __restrict__ models, int nh, float thr2,
+                                                    int* __restrict__ counts)
 {
+    const int n = resolve_n(n_max, d_n);
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int tl = t < nh ? t : nh - 1;
     float f[9];
@@ -334,11 +346,13 @@ struct FinalOut {
 };
 
 __global__ __launch_bounds__(64) void ransac_final_solve(const float* __restrict__ xy1, const float* __restrict__ xy2,
-                                                         int n, uint64_t seed, const unsigned long long* __restrict__ key,
+                                                         int n_max, const int* __restrict__ d_n, uint64_t seed,
+                                                         const unsigned long long* __restrict__ key,
                                                          FinalOut* __restrict__ fo)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const unsigned long long k = *key;
+    const int n = resolve_n(n_max, d_n);
+    const unsigned long long k = n >= 8 ? *key : 0ull;
     double F[9];
     bool ok = false;
 #pragma unroll
@@ -355,9 +369,10 @@ __global__ __launch_bounds__(64) void ransac_final_solve(const float* __restrict
 
 template <int KIND>
 __global__ __launch_bounds__(256) void ransac_final_mask(const float* __restrict__ xy1, const float* __restrict__ xy2,
-                                                         int n, float thr2, FinalOut* __restrict__ fo,
-                                                         uint8_t* __restrict__ mask)
+                                                         int n_max, const int* __restrict__ d_n, float thr2,
+                                                         FinalOut* __restrict__ fo, uint8_t* __restrict__ mask)
 {
+    const int n = resolve_n(n_max, d_n);
     const int i = blockIdx.x * 256 + threadIdx.x;
     float f[9];
 #pragma unroll
@@ -368,7 +383,7 @@ __global__ __launch_bounds__(256) void ransac_final_mask(const float* __restrict
         const float2 pp = *reinterpret_cast<const float2*>(xy2 + 2 * static_cast<size_t>(i));
         in = inlier32<KIND>(f, p.x, p.y, pp.x, pp.y, thr2);
     }
-    if (i < n) mask[i] = in ? 1 : 0;
+    if (i < n_max) mask[i] = in ? 1 : 0;
     const unsigned long long b = __ballot(in);
     if ((threadIdx.x & 63) == 0 && b) atomicAdd(&fo->n_inliers, __popcll(b));
 }
@@ -385,8 +400,8 @@ int check_params(const pm_ransac_params* p)
 }
 
 // score the shard; arena must already hold room.  d_key is zeroed here.
-int score_shard(pm_ctx* ctx, const float* dxy1, const float* dxy2, int n, const pm_ransac_params* p,
-                unsigned long long* d_key, char* scratch)
+int score_shard(pm_ctx* ctx, const float* dxy1, const float* dxy2, int n, const int* d_n,
+                const pm_ransac_params* p, unsigned long long* d_key, char* scratch)
 {
     const int nh = static_cast<int>(p->hyp_end - p->hyp_begin);
     PM_HIP_CHECK(hipMemsetAsync(d_key, 0, sizeof(unsigned long long), ctx->stream));
@@ -396,7 +411,7 @@ int score_shard(pm_ctx* ctx, const float* dxy1, const float* dxy2, int n, const 
     PM_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(int) * nh, ctx->stream));
     {
         pm::ScopedKernelTime t(ctx, "ransac_solve");
-        hipLaunchKernelGGL(ransac_solve, dim3((nh + 63) / 64), dim3(64), 0, ctx->stream, dxy1, dxy2, n, p->seed,
+        hipLaunchKernelGGL(ransac_solve, dim3((nh + 63) / 64), dim3(64), 0, ctx->stream, dxy1, dxy2, n, d_n, p->seed,
                            p->hyp_begin, nh, models);
         PM_HIP_CHECK(hipGetLastError());
     }
@@ -413,10 +428,10 @@ int score_shard(pm_ctx* ctx, const float* dxy1, const float* dxy2, int n, const 
         pm::ScopedKernelTime t(ctx, "ransac_score");
         if (p->error_kind == PM_ERR_SAMPSON)
             hipLaunchKernelGGL(ransac_score<PM_ERR_SAMPSON>, dim3(hb, chunks), dim3(256), 0, ctx->stream, dxy1, dxy2, n,
-                               chunk_len, models, nh, thr2, counts);
+                               d_n, chunk_len, models, nh, thr2, counts);
         else
             hipLaunchKernelGGL(ransac_score<PM_ERR_SYM_EPIPOLAR>, dim3(hb, chunks), dim3(256), 0, ctx->stream, dxy1,
-                               dxy2, n, chunk_len, models, nh, thr2, counts);
+                               dxy2, n, d_n, chunk_len, models, nh, thr2, counts);
         PM_HIP_CHECK(hipGetLastError());
     }
     {
@@ -433,18 +448,19 @@ size_t shard_scratch_bytes(const pm_ransac_params* p)
     return pm::align_up(sizeof(float) * MODEL_STRIDE * nh, 256) + pm::align_up(sizeof(int) * nh, 256) + 256;
 }
 
-int finalize(pm_ctx* ctx, const float* dxy1, const float* dxy2, int n, const pm_ransac_params* p,
+int finalize(pm_ctx* ctx, const float* dxy1, const float* dxy2, int n, const int* d_n, const pm_ransac_params* p,
              const unsigned long long* d_key, FinalOut* d_fo, uint8_t* d_mask)
 {
     pm::ScopedKernelTime t(ctx, "ransac_final");
-    hipLaunchKernelGGL(ransac_final_solve, dim3(1), dim3(64), 0, ctx->stream, dxy1, dxy2, n, p->seed, d_key, d_fo);
+    hipLaunchKernelGGL(ransac_final_solve, dim3(1), dim3(64), 0, ctx->stream, dxy1, dxy2, n, d_n, p->seed, d_key,
+                       d_fo);
     const float thr2 = p->thresh_px * p->thresh_px;
     if (p->error_kind == PM_ERR_SAMPSON)
         hipLaunchKernelGGL(ransac_final_mask<PM_ERR_SAMPSON>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, dxy1,
-                           dxy2, n, thr2, d_fo, d_mask);
+                           dxy2, n, d_n, thr2, d_fo, d_mask);
     else
         hipLaunchKernelGGL(ransac_final_mask<PM_ERR_SYM_EPIPOLAR>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream,
-                           dxy1, dxy2, n, thr2, d_fo, d_mask);
+                           dxy1, dxy2, n, d_n, thr2, d_fo, d_mask);
     PM_HIP_CHECK(hipGetLastError());
     return PM_OK;
 }
@@ -484,7 +500,7 @@ int host_run(pm_ctx* ctx, const float* xy1, const float* xy2, int n, const pm_ra
     PM_HIP_CHECK(hipMemcpyAsync(dxy1, xy1, xyb, hipMemcpyHostToDevice, ctx->stream));
     PM_HIP_CHECK(hipMemcpyAsync(dxy2, xy2, xyb, hipMemcpyHostToDevice, ctx->stream));
     if (hyp < 0) {
-        rc = score_shard(ctx, dxy1, dxy2, n, p, dkey, scratch);
+        rc = score_shard(ctx, dxy1, dxy2, n, nullptr, p, dkey, scratch);
         if (rc != PM_OK) return rc;
     } else {
         const unsigned long long k = pm_ransac_key(0u, static_cast<uint32_t>(hyp)) | (1ull << 32);  // non-zero
@@ -492,7 +508,7 @@ int host_run(pm_ctx* ctx, const float* xy1, const float* xy2, int n, const pm_ra
         *hk = k;
         PM_HIP_CHECK(hipMemcpyAsync(dkey, hk, 8, hipMemcpyHostToDevice, ctx->stream));
     }
-    rc = finalize(ctx, dxy1, dxy2, n, p, dkey, dfo, dmask);
+    rc = finalize(ctx, dxy1, dxy2, n, nullptr, p, dkey, dfo, dmask);
     if (rc != PM_OK) return rc;
     char* hp = static_cast<char*>(ctx->pinned);
     FinalOut* hfo = reinterpret_cast<FinalOut*>(hp + 8);
@@ -546,5 +562,42 @@ extern "C" int pm_ransac_score_dev(pm_ctx* ctx, const float* d_xy1, const float*
     pm::arena_reset(ctx);
     char* scratch = static_cast<char*>(pm::arena_take(ctx, shard_scratch_bytes(p)));
     PM_REQUIRE(scratch != nullptr, PM_E_NOMEM, "scratch arena too small");
-    return score_shard(ctx, d_xy1, d_xy2, n, p, reinterpret_cast<unsigned long long*>(d_best_key), scratch);
+    return score_shard(ctx, d_xy1, d_xy2, n, nullptr, p, reinterpret_cast<unsigned long long*>(d_best_key), scratch);
+}
+
+extern "C" int pm_ransac_score_devn(pm_ctx* ctx, const float* d_xy1, const float* d_xy2, int n_max,
+                                    const int32_t* d_n, const pm_ransac_params* p, uint64_t* d_best_key)
+{
+    PM_REQUIRE(ctx != nullptr && d_best_key != nullptr && d_n != nullptr, PM_E_INVALID, "null argument");
+    int rc = check_params(p);
+    if (rc != PM_OK) return rc;
+    PM_REQUIRE(n_max >= 1 && d_xy1 && d_xy2, PM_E_INVALID, "bad point arrays");
+    PM_HIP_CHECK(hipSetDevice(ctx->device));
+    rc = pm::arena_reserve(ctx, shard_scratch_bytes(p) + 1024);
+    if (rc != PM_OK) return rc;
+    pm::arena_reset(ctx);
+    char* scratch = static_cast<char*>(pm::arena_take(ctx, shard_scratch_bytes(p)));
+    PM_REQUIRE(scratch != nullptr, PM_E_NOMEM, "scratch arena too small");
+    return score_shard(ctx, d_xy1, d_xy2, n_max, d_n, p, reinterpret_cast<unsigned long long*>(d_best_key), scratch);
+}
+
+extern "C" int pm_ransac_model_from_key_dev(pm_ctx* ctx, const float* d_xy1, const float* d_xy2, int n_max,
+                                            const int32_t* d_n, const pm_ransac_params* p, const uint64_t* d_key,
+                                            double* d_F, uint8_t* d_mask, int32_t* d_n_inliers)
+{
+    PM_REQUIRE(ctx && d_xy1 && d_xy2 && d_key && d_F && d_mask && d_n_inliers, PM_E_INVALID, "null argument");
+    int rc = check_params(p);
+    if (rc != PM_OK) return rc;
+    PM_REQUIRE(n_max >= 1, PM_E_INVALID, "n_max must be positive");
+    PM_HIP_CHECK(hipSetDevice(ctx->device));
+    rc = pm::arena_reserve(ctx, sizeof(FinalOut) + 1024);
+    if (rc != PM_OK) return rc;
+    pm::arena_reset(ctx);
+    FinalOut* dfo = static_cast<FinalOut*>(pm::arena_take(ctx, sizeof(FinalOut)));
+    PM_REQUIRE(dfo != nullptr, PM_E_NOMEM, "scratch arena too small");
+    rc = finalize(ctx, d_xy1, d_xy2, n_max, d_n, p, reinterpret_cast<const unsigned long long*>(d_key), dfo, d_mask);
+    if (rc != PM_OK) return rc;
+    PM_HIP_CHECK(hipMemcpyAsync(d_F, dfo->F, sizeof(double) * 9, hipMemcpyDeviceToDevice, ctx->stream));
+    PM_HIP_CHECK(hipMemcpyAsync(d_n_inliers, &dfo->n_inliers, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+    return PM_OK;
 }

@@ -1,0 +1,86 @@
+"""GPU: the device-resident pipeline (matcher -> ratio filter + gather -> RANSAC with the count
+on the device -> finalisation) against the host-side stages and the oracle."""
+import numpy as np
+import pytest
+
+import points_matching_amd as pm
+from points_matching_amd import synth
+from util import assert_matches_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_pipeline_matches_host_stages(ctx, oracle):
+    import torch
+    dev = torch.device("cuda", 0)
+    w = synth.pair_workload(nq=1500, nt=1300, dim=128, seed=21, planted=0.4)
+    nq, nt, K = 1500, 1300, 2
+    s = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(s):
+        ctx.set_stream(s.cuda_stream)
+        d_q = torch.from_numpy(w["q"]).to(dev)
+        d_t = torch.from_numpy(w["t"]).to(dev)
+        d_kp1 = torch.from_numpy(w["kp1"]).to(dev)
+        d_kp2 = torch.from_numpy(w["kp2"]).to(dev)
+        d_knn = torch.empty((nq, K, 4), dtype=torch.int32, device=dev)
+        d_good = torch.zeros((nq, 4), dtype=torch.int32, device=dev)
+        d_xy1 = torch.zeros((nq, 2), dtype=torch.float32, device=dev)
+        d_xy2 = torch.zeros((nq, 2), dtype=torch.float32, device=dev)
+        d_n = torch.zeros(1, dtype=torch.int32, device=dev)
+        d_key = torch.zeros(1, dtype=torch.int64, device=dev)
+        d_F = torch.zeros(9, dtype=torch.float64, device=dev)
+        d_mask = torch.full((nq,), 7, dtype=torch.uint8, device=dev)
+        d_ninl = torch.zeros(1, dtype=torch.int32, device=dev)
+        s.synchronize()
+        ctx.bf_knn_l2_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, 128, K, d_knn.data_ptr())
+        ctx.filter_ratio_gather_dev(d_knn.data_ptr(), nq, K, 0.8, d_kp1.data_ptr(), d_kp2.data_ptr(),
+                                    d_good.data_ptr(), d_xy1.data_ptr(), d_xy2.data_ptr(), d_n.data_ptr())
+        ctx.ransac_score_devn(d_xy1.data_ptr(), d_xy2.data_ptr(), nq, d_n.data_ptr(), 0, 800, 1.0, 11,
+                              d_key.data_ptr())
+        ctx.ransac_model_from_key_dev(d_xy1.data_ptr(), d_xy2.data_ptr(), nq, d_n.data_ptr(), 1.0, 11,
+                                      d_key.data_ptr(), d_F.data_ptr(), d_mask.data_ptr(), d_ninl.data_ptr())
+        ctx.synchronize()
+        ctx.set_stream(0)
+    knn = d_knn.cpu().numpy().view(pm.MATCH_DTYPE).reshape(nq, K)
+    want_knn = oracle.bf_knn_l2(w["q"], w["t"], K)
+    assert_matches_equal(knn, want_knn, "dev knn")
+    good_o = oracle.filter_ratio(want_knn, 0.8)
+    n = int(d_n.item())
+    assert n == good_o.size
+    assert_matches_equal(d_good.cpu().numpy().view(pm.MATCH_DTYPE).reshape(-1)[:n], good_o, "dev ratio")
+    xy1 = oracle.gather_points(w["kp1"], good_o["queryIdx"])
+    xy2 = oracle.gather_points(w["kp2"], good_o["trainIdx"])
+    assert (d_xy1.cpu().numpy()[:n] == xy1).all() and (d_xy2.cpu().numpy()[:n] == xy2).all()
+    rc, F, mask, ninl, key = oracle.ransac_fundamental(xy1, xy2, 800, 1.0, 11)
+    assert int(d_key.item()) == key and int(d_ninl.item()) == ninl
+    assert (d_mask.cpu().numpy()[:n] == mask).all() and not d_mask.cpu().numpy()[n:].any()
+    assert (d_F.cpu().numpy().view(np.uint64) == F.reshape(9).view(np.uint64)).all()
+
+
+def test_concat_points(ctx):
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(0)
+    parts, stride = 3, 100
+    a = rng.random((parts, stride, 2)).astype(np.float32)
+    b = rng.random((parts, stride, 2)).astype(np.float32)
+    counts = np.array([40, 0, 100], np.int32)
+    d_a, d_b, d_c = (torch.from_numpy(x).to(dev) for x in (a, b, counts))
+    o1 = torch.zeros((parts * stride, 2), dtype=torch.float32, device=dev)
+    o2 = torch.zeros_like(o1)
+    d_n = torch.zeros(1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.concat_points_dev(d_a.data_ptr(), d_b.data_ptr(), d_c.data_ptr(), parts, stride, o1.data_ptr(),
+                          o2.data_ptr(), d_n.data_ptr())
+    ctx.synchronize()
+    assert int(d_n.item()) == 140
+    want1 = np.concatenate([a[p, :counts[p]] for p in range(parts)])
+    want2 = np.concatenate([b[p, :counts[p]] for p in range(parts)])
+    assert (o1.cpu().numpy()[:140] == want1).all() and (o2.cpu().numpy()[:140] == want2).all()
+
+
+def test_knn_stats_report_refinement(ctx):
+    q, t, _ = synth.surf_like(1024, 1024, 128, seed=2)
+    ctx.bf_knn_l2(q, t, 2)
+    st = ctx.knn_stats()
+    assert st["nonfinite"] == 0 and st["rescans"] < 32      # the MFMA route, not the re-scan, did the work
