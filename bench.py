@@ -51,7 +51,7 @@ def main():
     import torch
     import torch.distributed as dist
     import points_matching_amd as pm
-    from points_matching_amd import synth
+    from points_matching_amd import shard, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -95,8 +95,7 @@ def main():
         a_xy1 = torch.zeros((n_all_max, 2), dtype=torch.float32, device=dev)
         a_xy2 = torch.zeros((n_all_max, 2), dtype=torch.float32, device=dev)
         a_n = torch.zeros(1, dtype=torch.int32, device=dev)
-    hb = rank * H // world
-    he = (rank + 1) * H // world
+    hb, he = shard.hyp_shard(H, rank, world)
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
 
@@ -109,9 +108,7 @@ def main():
         if e:
             e[1].record(stream)
         if world > 1:
-            dist.all_gather_into_tensor(g_xy1, d_xy1)
-            dist.all_gather_into_tensor(g_xy2, d_xy2)
-            dist.all_gather_into_tensor(g_n, d_n)
+            shard.gather_blocks(d_xy1, d_xy2, d_n, g_xy1, g_xy2, g_n)
             ctx.concat_points_dev(g_xy1.data_ptr(), g_xy2.data_ptr(), g_n.data_ptr(), world, nq,
                                   a_xy1.data_ptr(), a_xy2.data_ptr(), a_n.data_ptr())
             x1, x2, nn = a_xy1, a_xy2, a_n
@@ -120,7 +117,7 @@ def main():
         ctx.ransac_score_devn(x1.data_ptr(), x2.data_ptr(), n_all_max, nn.data_ptr(), hb, he, thresh, seed,
                               d_key.data_ptr())
         if world > 1:
-            dist.all_reduce(d_key, op=dist.ReduceOp.MAX)      # the single 8-byte exchange
+            shard.reduce_key(d_key)                            # the single 8-byte exchange
         ctx.ransac_model_from_key_dev(x1.data_ptr(), x2.data_ptr(), n_all_max, nn.data_ptr(), thresh, seed,
                                       d_key.data_ptr(), d_F.data_ptr(), d_mask.data_ptr(), d_ninl.data_ptr())
         if e:

@@ -1,0 +1,194 @@
+// pm_cli — C++ host of the MI355X-native matcher: the counterpart of the reference's main()
+// (`Points Matching/main.cpp:9-147`) for the hot path main.cpp:42-123.  It keeps the reference's
+// stdout surface (main.cpp:58-59, :73, :76, :119, :123) and calls the HIP kernels only through
+// the C ABI of include/pm.h.  Image decoding and SURF (main.cpp:11-40) are out of scope
+// (DESIGN.md §0): descriptors and keypoints come from binary matrix files.
+//
+//   pm_cli --desc1 a.pmm --desc2 b.pmm --kp1 ka.pmm --kp2 kb.pmm
+//          [--filter midpoint|ratio] [--ratio 0.8] [--iters 10000] [--thresh 1.0] [--seed 24301]
+//          [--f-scale opencv|unit] [--device 0] [--quiet] [--json]
+//
+// .pmm file: magic "PMM1", int32 rows, int32 cols, int32 dtype (0 = float32, 1 = uint8), data
+// row-major.  float32 descriptors -> BF-L2 (main.cpp:43), uint8 -> BF-Hamming.
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "pm.h"
+
+namespace {
+
+struct Matrix {
+    int rows = 0, cols = 0, dtype = 0;
+    std::vector<unsigned char> data;
+    const float* f32() const { return reinterpret_cast<const float*>(data.data()); }
+};
+
+bool load_matrix(const std::string& path, Matrix& m)
+{
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) { fprintf(stderr, "pm_cli: cannot open %s\n", path.c_str()); return false; }
+    char magic[4];
+    int32_t hdr[3];
+    bool ok = fread(magic, 1, 4, f) == 4 && memcmp(magic, "PMM1", 4) == 0 && fread(hdr, 4, 3, f) == 3;
+    if (ok) {
+        m.rows = hdr[0]; m.cols = hdr[1]; m.dtype = hdr[2];
+        ok = m.rows >= 0 && m.cols > 0 && (m.dtype == 0 || m.dtype == 1);
+    }
+    if (ok) {
+        const size_t bytes = static_cast<size_t>(m.rows) * m.cols * (m.dtype == 0 ? 4 : 1);
+        m.data.resize(bytes);
+        ok = fread(m.data.data(), 1, bytes, f) == bytes;
+    }
+    fclose(f);
+    if (!ok) fprintf(stderr, "pm_cli: %s is not a valid .pmm matrix\n", path.c_str());
+    return ok;
+}
+
+int fail(const char* what, int rc)
+{
+    fprintf(stderr, "pm_cli: %s failed: %s (%s)\n", what, pm_status_string(rc), pm_last_error());
+    return 1;
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    std::string desc1, desc2, kp1, kp2, filter = "midpoint", fscale = "opencv";
+    float ratio = 0.8f, thresh = 1.0f;
+    long iters = 10000;
+    unsigned long long seed = 0x5EED;
+    int device = 0;
+    bool quiet = false, json = false;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto val = [&](const char* name) -> const char* {
+            if (i + 1 >= argc) { fprintf(stderr, "pm_cli: %s needs a value\n", name); exit(2); }
+            return argv[++i];
+        };
+        if (a == "--desc1") desc1 = val("--desc1");
+        else if (a == "--desc2") desc2 = val("--desc2");
+        else if (a == "--kp1") kp1 = val("--kp1");
+        else if (a == "--kp2") kp2 = val("--kp2");
+        else if (a == "--filter") filter = val("--filter");
+        else if (a == "--ratio") ratio = strtof(val("--ratio"), nullptr);
+        else if (a == "--iters") iters = strtol(val("--iters"), nullptr, 0);
+        else if (a == "--thresh") thresh = strtof(val("--thresh"), nullptr);
+        else if (a == "--seed") seed = strtoull(val("--seed"), nullptr, 0);
+        else if (a == "--f-scale") fscale = val("--f-scale");
+        else if (a == "--device") device = atoi(val("--device"));
+        else if (a == "--quiet") quiet = true;
+        else if (a == "--json") json = true;
+        else { fprintf(stderr, "pm_cli: unknown option %s\n", a.c_str()); return 2; }
+    }
+    if (desc1.empty() || desc2.empty() || kp1.empty() || kp2.empty()) {
+        fprintf(stderr, "usage: pm_cli --desc1 A --desc2 B --kp1 KA --kp2 KB [--filter midpoint|ratio] "
+                        "[--ratio r] [--iters n] [--thresh px] [--seed s] [--f-scale opencv|unit]\n");
+        return 2;
+    }
+    Matrix d1, d2, k1, k2;
+    if (!load_matrix(desc1, d1) || !load_matrix(desc2, d2) || !load_matrix(kp1, k1) || !load_matrix(kp2, k2)) return 1;
+    if (d1.cols != d2.cols || d1.dtype != d2.dtype || k1.dtype != 0 || k2.dtype != 0 || k1.cols != 2 ||
+        k2.cols != 2 || k1.rows != d1.rows || k2.rows != d2.rows) {
+        fprintf(stderr, "pm_cli: inconsistent descriptor / keypoint matrices\n");
+        return 1;
+    }
+    const bool want_ratio = filter == "ratio";
+    if (!want_ratio && filter != "midpoint") { fprintf(stderr, "pm_cli: --filter midpoint|ratio\n"); return 2; }
+
+    pm_ctx* ctx = nullptr;
+    int rc = pm_ctx_create(device, &ctx);
+    if (rc != PM_OK) return fail("pm_ctx_create", rc);
+
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+
+    // ---- matcher.match(imageDesc1, imageDesc2, matchePoints, Mat())            main.cpp:42-46
+    const int k = want_ratio ? 2 : 1;
+    std::vector<pm_match> knn(static_cast<size_t>(d1.rows) * k);
+    if (d1.dtype == 0)
+        rc = pm_bf_knn_l2_f32(ctx, d1.f32(), d1.rows, d2.f32(), d2.rows, d1.cols, k, 0, knn.data());
+    else
+        rc = pm_bf_knn_hamming_u8(ctx, d1.data.data(), d1.rows, d2.data.data(), d2.rows, d1.cols, k, knn.data());
+    if (rc != PM_OK) return fail("matcher", rc);
+    const auto t1 = clk::now();
+
+    // ---- selecting strong features                                             main.cpp:48-69
+    std::vector<pm_match> good(static_cast<size_t>(d1.rows) + 1);
+    int n_good = 0;
+    if (want_ratio) {
+        rc = pm_filter_ratio(knn.data(), d1.rows, k, ratio, good.data(), &n_good);
+    } else {
+        // OpenCV drops queries without a neighbour (empty train set): keep only matched rows
+        std::vector<pm_match> matched;
+        for (const pm_match& m : knn) if (m.trainIdx >= 0) matched.push_back(m);
+        double lo = 0, hi = 0;
+        rc = pm_filter_midpoint(matched.data(), static_cast<int>(matched.size()), &lo, &hi, good.data(), &n_good);
+        if (rc == PM_OK && !quiet) {
+            // main.cpp:58-59; the full-width colon of the source is not representable in the
+            // reference's code page and its binary prints '?' 
+            std::cout << "The Best Match is? " << lo << std::endl;
+            std::cout << "The Worst Match is? " << hi << std::endl;
+        }
+    }
+    if (rc != PM_OK) return fail("filter", rc);
+    good.resize(n_good);
+
+    // ---- match list + index vectors + KeyPoint::convert                        main.cpp:71-79, 89-91
+    std::vector<int32_t> qi(n_good), ti(n_good);
+    std::vector<float> xy1(2 * static_cast<size_t>(n_good)), xy2(2 * static_cast<size_t>(n_good));
+    rc = pm_match_indices(good.data(), n_good, qi.data(), ti.data());
+    if (rc == PM_OK) rc = pm_gather_points(k1.f32(), k1.rows, qi.data(), n_good, xy1.data());
+    if (rc == PM_OK) rc = pm_gather_points(k2.f32(), k2.rows, ti.data(), n_good, xy2.data());
+    if (rc != PM_OK) return fail("gather", rc);
+    if (!quiet) {
+        const long need = pm_format_match_list(good.data(), n_good, nullptr, 0);
+        std::string text(static_cast<size_t>(need) + 1, '\0');
+        pm_format_match_list(good.data(), n_good, &text[0], text.size());
+        fputs(text.c_str(), stdout);
+    }
+    const auto t2 = clk::now();
+
+    // ---- cv::findFundamentalMat(...)                                           main.cpp:94-98
+    double F[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<uint8_t> mask(static_cast<size_t>(n_good) + 1);
+    int n_inl = 0;
+    uint64_t key = 0;
+    pm_ransac_params prm;
+    prm.hyp_begin = 0; prm.hyp_end = iters; prm.seed = seed; prm.thresh_px = thresh; prm.error_kind = PM_ERR_SAMPSON;
+    rc = pm_ransac_fundamental(ctx, xy1.data(), xy2.data(), n_good, &prm, F, mask.data(), &n_inl, &key);
+    if (rc != PM_OK && rc != PM_E_TOO_FEW && rc != PM_E_NO_MODEL) return fail("pm_ransac_fundamental", rc);
+    // like cv::findFundamentalMat, a failed estimate yields the zero matrix
+    const auto t3 = clk::now();
+    if (fscale == "opencv") pm_f_scale_f33(F);
+
+    // ---- residual report, the reference's x1^T F x2 form                       main.cpp:101-123
+    std::vector<double> res(static_cast<size_t>(n_good) + 1);
+    double mean_abs = 0;
+    rc = pm_epipolar_residuals(xy1.data(), xy2.data(), n_good, F, /*transposed=*/1, res.data(), &mean_abs);
+    if (rc != PM_OK) return fail("pm_epipolar_residuals", rc);
+    if (!quiet) {
+        for (int i = 0; i < n_good; ++i) std::cout << "result = " << i << " " << res[i] << std::endl;   // :119
+        std::cout << "The average value is  " << mean_abs << std::endl;                                 // :123
+    }
+    if (json) {
+        auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        double mean_fwd = 0;
+        pm_epipolar_residuals(xy1.data(), xy2.data(), n_good, F, 0, nullptr, &mean_fwd);
+        printf("{\"n1\": %d, \"n2\": %d, \"dim\": %d, \"matches\": %d, \"inliers\": %d, \"best_hyp\": %u, "
+               "\"ransac_status\": %d, \"mean_abs_x1Fx2\": %.17g, \"mean_abs_x2Fx1\": %.17g, "
+               "\"ms\": {\"match\": %.3f, \"filter_gather\": %.3f, \"ransac\": %.3f}, "
+               "\"F\": [%.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g]}\n",
+               d1.rows, d2.rows, d1.cols, n_good, n_inl, key ? pm_ransac_key_hyp(key) : 0u, rc == PM_OK ? 0 : rc,
+               mean_abs, mean_fwd, ms(t0, t1), ms(t1, t2), ms(t2, t3), F[0], F[1], F[2], F[3], F[4], F[5], F[6],
+               F[7], F[8]);
+    }
+    pm_ctx_destroy(ctx);
+    return 0;
+}

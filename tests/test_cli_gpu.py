@@ -1,0 +1,54 @@
+"""GPU: the C++ host tool (points_matching_amd/host/pm_cli.cpp, counterpart of the reference's
+main()) prints the reference's stdout surface (main.cpp:58-59, :73, :76, :119, :123) with the
+values the oracle computes."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from points_matching_amd import build, io, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _g(x):
+    return "%g" % x          # iostream default formatting (precision 6)
+
+
+@pytest.mark.parametrize("mode", ["midpoint", "ratio"])
+def test_cli_stdout_matches_reference_format(tmp_path, oracle, mode):
+    exe = build.HOST_BIN
+    assert os.path.exists(exe), "run python -m points_matching_amd.build"
+    w = synth.pair_workload(nq=300, nt=280, dim=128, seed=77, planted=0.5, kind="surf")
+    paths = {}
+    for name in ("q", "t", "kp1", "kp2"):
+        paths[name] = str(tmp_path / (name + ".pmm"))
+        io.save_pmm(paths[name], w[name])
+    cmd = [exe, "--desc1", paths["q"], "--desc2", paths["t"], "--kp1", paths["kp1"], "--kp2", paths["kp2"],
+           "--filter", mode, "--iters", "400", "--thresh", "1.0", "--seed", "99", "--json"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.splitlines()
+
+    if mode == "midpoint":
+        knn = oracle.bf_knn_l2(w["q"], w["t"], 1).reshape(-1)
+        good, mn, mx = oracle.filter_midpoint(knn)
+        exp = ["The Best Match is? " + _g(mn), "The Worst Match is? " + _g(mx)]
+    else:
+        good = oracle.filter_ratio(oracle.bf_knn_l2(w["q"], w["t"], 2), 0.8)
+        exp = []
+    exp += oracle.format_match_list(good).splitlines()
+    xy1 = oracle.gather_points(w["kp1"], good["queryIdx"])
+    xy2 = oracle.gather_points(w["kp2"], good["trainIdx"])
+    rc, F, mask, ninl, key = oracle.ransac_fundamental(xy1, xy2, 400, 1.0, 99)
+    F = oracle.f_scale_f33(F)
+    r, mean = oracle.epipolar_residuals(xy1, xy2, F, 1)
+    exp += ["result = %d %s" % (i, _g(r[i])) for i in range(good.size)]
+    exp += ["The average value is  " + _g(mean)]
+    assert lines[:-1] == exp
+    js = json.loads(lines[-1])
+    assert js["matches"] == good.size and js["inliers"] == ninl
+    assert js["best_hyp"] == 0xFFFFFFFF - (key & 0xFFFFFFFF)
+    assert np.array_equal(np.array(js["F"]), F.reshape(9))

@@ -1,0 +1,79 @@
+"""Golden fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py from the oracle):
+CPU — the oracle still reproduces them; GPU — the HIP path reproduces them bit for bit."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+
+
+def _load(name):
+    return np.load(os.path.join(GOLD, name), allow_pickle=False)
+
+
+def _knn_cases():
+    return [("knn_l2_sift_256x256x128.npz", 2), ("knn_l2_surf_96x160x128.npz", 2),
+            ("knn_l2_surf_40x50x20_k3.npz", 3)]
+
+
+def test_fixtures_present():
+    assert len(glob.glob(os.path.join(GOLD, "*.npz"))) == 7
+
+
+@pytest.mark.parametrize("name,k", _knn_cases())
+def test_oracle_reproduces_knn_l2(oracle, name, k):
+    g = _load(name)
+    m = oracle.bf_knn_l2(g["q"].astype(np.float32), g["t"].astype(np.float32), k)
+    assert (m["trainIdx"] == g["idx"]).all() and (m["distance"].view(np.uint32) == g["dist_bits"]).all()
+
+
+def test_oracle_reproduces_hamming(oracle):
+    g = _load("knn_hamming_256x256x32.npz")
+    m = oracle.bf_knn_hamming(g["q"], g["t"], 2)
+    assert (m["trainIdx"] == g["idx"]).all() and (m["distance"] == g["dist"]).all()
+
+
+@pytest.mark.parametrize("name", ["clean", "noisy", "outliers"])
+def test_oracle_reproduces_twoview(oracle, name):
+    g = _load("twoview_N512_%s.npz" % name)
+    for h in range(16):
+        assert (oracle.sample8(0x5EED, h, 512) == g["samples_h0_15"][h]).all()
+    for kind in (0, 1):
+        rc, F, mask, n, key = oracle.ransac_fundamental(g["xy1"], g["xy2"], 500, 1.0, 0x5EED, kind)
+        assert rc == 0 and key == int(g["key_%d" % kind][0])
+        assert (F.reshape(9).view(np.uint64) == g["F_bits_%d" % kind]).all()
+        assert (mask == g["mask_%d" % kind]).all()
+    if name == "clean":
+        assert g["mask_0"].all()
+        F = g["F_bits_0"].view(np.float64).reshape(3, 3)
+        assert min(np.abs(F - g["F_gt"]).max(), np.abs(F + g["F_gt"]).max()) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,k", _knn_cases())
+def test_hip_reproduces_knn_l2(ctx, name, k):
+    g = _load(name)
+    for flags in (0, 1):
+        m = ctx.bf_knn_l2(g["q"].astype(np.float32), g["t"].astype(np.float32), k, flags)
+        assert (m["trainIdx"] == g["idx"]).all() and (m["distance"].view(np.uint32) == g["dist_bits"]).all()
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_hamming(ctx):
+    g = _load("knn_hamming_256x256x32.npz")
+    m = ctx.bf_knn_hamming(g["q"], g["t"], 2)
+    assert (m["trainIdx"] == g["idx"]).all() and (m["distance"] == g["dist"]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["clean", "noisy", "outliers"])
+def test_hip_reproduces_twoview(ctx, name):
+    g = _load("twoview_N512_%s.npz" % name)
+    for kind in (0, 1):
+        rc, F, mask, n, key = ctx.ransac_fundamental(g["xy1"], g["xy2"], 500, 1.0, 0x5EED, kind)
+        assert rc == 0 and key == int(g["key_%d" % kind][0])
+        assert (F.reshape(9).view(np.uint64) == g["F_bits_%d" % kind]).all()
+        assert (mask == g["mask_%d" % kind]).all()
