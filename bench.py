@@ -114,12 +114,15 @@ def main():
             x1, x2, nn = a_xy1, a_xy2, a_n
         else:
             x1, x2, nn = d_xy1, d_xy2, d_n
-        ctx.ransac_score_devn(x1.data_ptr(), x2.data_ptr(), n_all_max, nn.data_ptr(), hb, he, thresh, seed,
-                              d_key.data_ptr())
         if world > 1:
+            ctx.ransac_score_devn(x1.data_ptr(), x2.data_ptr(), n_all_max, nn.data_ptr(), hb, he, thresh, seed,
+                                  d_key.data_ptr())
             shard.reduce_key(d_key)                            # the single 8-byte exchange
-        ctx.ransac_model_from_key_dev(x1.data_ptr(), x2.data_ptr(), n_all_max, nn.data_ptr(), thresh, seed,
-                                      d_key.data_ptr(), d_F.data_ptr(), d_mask.data_ptr(), d_ninl.data_ptr())
+            ctx.ransac_model_from_key_dev(x1.data_ptr(), x2.data_ptr(), n_all_max, nn.data_ptr(), thresh, seed,
+                                          d_key.data_ptr(), d_F.data_ptr(), d_mask.data_ptr(), d_ninl.data_ptr())
+        else:
+            ctx.ransac_run_dev(x1.data_ptr(), x2.data_ptr(), n_all_max, nn.data_ptr(), hb, he, thresh, seed,
+                               d_key.data_ptr(), d_F.data_ptr(), d_mask.data_ptr(), d_ninl.data_ptr())
         if e:
             e[2].record(stream)
 
@@ -164,8 +167,10 @@ def main():
             kern[name] = round(ms * 1e3, 2)           # microseconds
     ctx.timing_enable(False)
     # diagnostics of the coarse/refine split (a kNN call on its own, so the arena still holds them)
+    ctx.knn_diag_enable(True)
     ctx.bf_knn_l2_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, K, d_knn.data_ptr())
     kstats = ctx.knn_stats()
+    ctx.knn_diag_enable(False)
 
     # ---- parity spot check against the CPU oracle (untimed; checker only)
     parity = "skipped"

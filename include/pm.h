@@ -71,8 +71,10 @@ int  pm_ctx_synchronize(pm_ctx* ctx);
 int  pm_ctx_timing_enable(pm_ctx* ctx, int enable);
 int  pm_ctx_timing_reset(pm_ctx* ctx);
 int  pm_ctx_timing_get(pm_ctx* ctx, const char* kernel, double* mean_ms, int* launches);
-/* Diagnostics of the last pm_bf_knn_l2_f32[_dev] call on this context (synchronises):
- * queries that took the exact re-scan branch of the refinement, and the non-finite-input flag. */
+/* Diagnostics of the MFMA route of pm_bf_knn_l2_f32[_dev]: while enabled, each call records how
+ * many queries took the exact re-scan branch of the refinement and whether a non-finite input
+ * was seen; pm_ctx_knn_stats returns the values of the last such call (synchronises). */
+int  pm_ctx_knn_diag_enable(pm_ctx* ctx, int enable);
 int  pm_ctx_knn_stats(pm_ctx* ctx, int* rescans, int* nonfinite);
 const char* pm_last_error(void);       /* thread-local text of the last PM_E_HIP / PM_E_* */
 const char* pm_status_string(int status);
@@ -172,6 +174,12 @@ int pm_ransac_score_dev(pm_ctx* ctx, const float* d_xy1, const float* d_xy2, int
  * leaves *d_best_key = 0. */
 int pm_ransac_score_devn(pm_ctx* ctx, const float* d_xy1, const float* d_xy2, int n_max,
                          const int32_t* d_n, const pm_ransac_params* p, uint64_t* d_best_key);
+/* Whole single-shard run on the device: solve + score [hyp_begin, hyp_end), pick the winner and
+ * publish its key, F (9 doubles), mask (n_max bytes, zero beyond n) and inlier count — the
+ * device-resident equivalent of pm_ransac_fundamental.  d_n may be NULL (n = n_max). */
+int pm_ransac_run_dev(pm_ctx* ctx, const float* d_xy1, const float* d_xy2, int n_max,
+                      const int32_t* d_n, const pm_ransac_params* p, uint64_t* d_best_key,
+                      double* d_F, uint8_t* d_mask, int32_t* d_n_inliers);
 /* Device-resident finalisation: F (9 doubles), mask (n_max bytes, zero beyond n) and inlier
  * count of the hypothesis encoded in *d_key (e.g. the all-reduced winner).  d_n may be NULL
  * (then n = n_max).  A zero key / n < 8 gives F = 0, mask = 0, count 0. */

@@ -24,7 +24,7 @@ PM_OK, PM_E_INVALID, PM_E_TOO_FEW, PM_E_NO_MODEL, PM_E_HIP, PM_E_NOMEM, PM_E_UNS
 # every extern "C" symbol include/pm.h declares (tests check the library exports all of them)
 EXPORTS = [
     "pm_ctx_create", "pm_ctx_destroy", "pm_ctx_set_stream", "pm_ctx_synchronize",
-    "pm_ctx_timing_enable", "pm_ctx_timing_reset", "pm_ctx_timing_get", "pm_ctx_knn_stats",
+    "pm_ctx_timing_enable", "pm_ctx_timing_reset", "pm_ctx_timing_get", "pm_ctx_knn_diag_enable", "pm_ctx_knn_stats",
     "pm_last_error",
     "pm_status_string", "pm_version",
     "pm_bf_knn_l2_f32", "pm_bf_knn_l2_f32_dev", "pm_bf_knn_hamming_u8", "pm_bf_knn_hamming_u8_dev",
@@ -32,7 +32,7 @@ EXPORTS = [
     "pm_format_match_list",
     "pm_filter_ratio_gather_dev", "pm_concat_points_dev",
     "pm_ransac_fundamental", "pm_ransac_score_dev", "pm_ransac_score_devn", "pm_ransac_model_from_hyp",
-    "pm_ransac_model_from_key_dev",
+    "pm_ransac_model_from_key_dev", "pm_ransac_run_dev",
     "pm_epipolar_residuals", "pm_f_scale_f33", "pm_epilines", "pm_epiline_endpoints",
 ]
 
@@ -214,6 +214,9 @@ class Context:
         _check(lib().pm_ctx_timing_get(self._h, name.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def knn_diag_enable(self, on=True):
+        _check(lib().pm_ctx_knn_diag_enable(self._h, int(on)))
+
     def knn_stats(self):
         r, nf = C.c_int(), C.c_int()
         _check(lib().pm_ctx_knn_stats(self._h, C.byref(r), C.byref(nf)))
@@ -236,6 +239,13 @@ class Context:
         prm = RansacParams(hyp_begin, hyp_end, seed, thresh_px, kind)
         _check(lib().pm_ransac_score_devn(self._h, C.c_void_p(dxy1_ptr), C.c_void_p(dxy2_ptr), n_max,
                                           C.c_void_p(dn_ptr), C.byref(prm), C.c_void_p(dkey_ptr)))
+
+    def ransac_run_dev(self, dxy1_ptr, dxy2_ptr, n_max, dn_ptr, hyp_begin, hyp_end, thresh_px, seed, dkey_ptr,
+                       dF_ptr, dmask_ptr, dninl_ptr, kind=PM_ERR_SAMPSON):
+        prm = RansacParams(hyp_begin, hyp_end, seed, thresh_px, kind)
+        _check(lib().pm_ransac_run_dev(self._h, C.c_void_p(dxy1_ptr), C.c_void_p(dxy2_ptr), n_max,
+                                       C.c_void_p(dn_ptr or 0), C.byref(prm), C.c_void_p(dkey_ptr),
+                                       C.c_void_p(dF_ptr), C.c_void_p(dmask_ptr), C.c_void_p(dninl_ptr)))
 
     def ransac_model_from_key_dev(self, dxy1_ptr, dxy2_ptr, n_max, dn_ptr, thresh_px, seed, dkey_ptr, dF_ptr,
                                   dmask_ptr, dninl_ptr, kind=PM_ERR_SAMPSON):

@@ -8,50 +8,72 @@
 
 namespace {
 
-// One workgroup of 1024 threads walks the rows in order; each pass compacts 1024 rows with a
-// ballot prefix inside the wave and a 16-entry scan across waves.
+// One workgroup of 1024 threads; a thread owns FG_ITEMS consecutive rows (a contiguous 256-byte
+// read at k = 2), so 8192 rows need a single scan: ballot-free local prefix + one wave scan + a
+// 16-entry scan across waves.  Longer inputs loop with a running base.
+constexpr int FG_ITEMS = 8;
+
 __global__ __launch_bounds__(1024) void filter_ratio_gather(const pm_match* __restrict__ knn, int nq, int k,
                                                             float ratio, const float* __restrict__ kp1,
                                                             const float* __restrict__ kp2,
                                                             pm_match* __restrict__ good, float* __restrict__ xy1,
                                                             float* __restrict__ xy2, int* __restrict__ n_out)
 {
-    __shared__ int wave_cnt[16];
+    __shared__ int wave_tot[16];
     __shared__ int base_sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) base_sh = 0;
     __syncthreads();
-    for (int start = 0; start < nq; start += 1024) {
-        const int i = start + tid;
-        bool keep = false;
-        pm_match best;
-        best.queryIdx = 0; best.trainIdx = -1; best.imgIdx = 0; best.distance = 0.f;
-        if (i < nq) {
-            best = knn[static_cast<size_t>(i) * k];
-            const pm_match second = knn[static_cast<size_t>(i) * k + 1];
-            const float rhs = ratio * second.distance;
-            keep = best.trainIdx >= 0 && second.trainIdx >= 0 && best.distance < rhs;
+    for (int start = 0; start < nq; start += 1024 * FG_ITEMS) {
+        const int i0 = start + tid * FG_ITEMS;
+        pm_match best[FG_ITEMS];
+        unsigned keep = 0u;
+        // unconditional loads from clamped rows (a load under a per-element branch makes hipcc wait
+        // for each one in turn); the row guard is applied to the flag instead
+        pm_match second[FG_ITEMS];
+#pragma unroll
+        for (int e = 0; e < FG_ITEMS; ++e) {
+            const int i = i0 + e < nq ? i0 + e : nq - 1;
+            best[e] = knn[static_cast<size_t>(i) * k];
+            second[e] = knn[static_cast<size_t>(i) * k + 1];
         }
-        const unsigned long long b = __ballot(keep);
-        const int before = __popcll(b & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_cnt[wave] = __popcll(b);
-        __syncthreads();
-        int off = base_sh;
-        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
-        if (keep) {
-            const int o = off + before;
-            good[o] = best;
+        float2 pa[FG_ITEMS], pb[FG_ITEMS];
+#pragma unroll
+        for (int e = 0; e < FG_ITEMS; ++e) {
+            const float rhs = ratio * second[e].distance;
+            const bool ok = i0 + e < nq && best[e].trainIdx >= 0 && second[e].trainIdx >= 0 && best[e].distance < rhs;
+            if (ok) keep |= 1u << e;
             if (kp1) {
-                xy1[2 * o] = kp1[2 * static_cast<size_t>(best.queryIdx)];
-                xy1[2 * o + 1] = kp1[2 * static_cast<size_t>(best.queryIdx) + 1];
-                xy2[2 * o] = kp2[2 * static_cast<size_t>(best.trainIdx)];
-                xy2[2 * o + 1] = kp2[2 * static_cast<size_t>(best.trainIdx) + 1];
+                const int ti = best[e].trainIdx >= 0 ? best[e].trainIdx : 0;
+                pa[e] = *reinterpret_cast<const float2*>(kp1 + 2 * static_cast<size_t>(best[e].queryIdx));
+                pb[e] = *reinterpret_cast<const float2*>(kp2 + 2 * static_cast<size_t>(ti));
             }
         }
+        const int mine = __popc(keep);
+        int incl = mine;                                    // inclusive scan over the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int off = base_sh + incl - mine;
+        for (int w = 0; w < wave; ++w) off += wave_tot[w];
+#pragma unroll
+        for (int e = 0; e < FG_ITEMS; ++e)
+            if (keep & (1u << e)) {
+                good[off] = best[e];
+                if (kp1) {
+                    *reinterpret_cast<float2*>(xy1 + 2 * static_cast<size_t>(off)) = pa[e];
+                    *reinterpret_cast<float2*>(xy2 + 2 * static_cast<size_t>(off)) = pb[e];
+                }
+                ++off;
+            }
         __syncthreads();
         if (tid == 0) {
             int tot = 0;
-            for (int w = 0; w < 16; ++w) tot += wave_cnt[w];
+            for (int w = 0; w < 16; ++w) tot += wave_tot[w];
             base_sh += tot;
         }
         __syncthreads();

@@ -105,61 +105,197 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
 }
 
 // ---------------------------------------------------------------------------------------------
-// prep: squared norms, 16 lanes per row.  stats[0] = max norm (float bits), stats[1] |= 1 when a
-// norm is not finite.  Approximate values only feed the coarse pass and its error bound.
+// prep: squared norms of the query rows and the train rows in ONE launch (64 rows per block, 16
+// lanes per row).  stats words are epoch-tagged 64-bit maxima, (epoch << 32) | payload, so a
+// call never has to clear them: values left by earlier calls carry a smaller epoch and lose.
+//   stats[0]: payload = float bits of the largest finite train norm
+//   stats[1]: payload = 1 when any norm is not finite
+// Approximate values: they only feed the coarse pass and its error bound.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void knn_l2_prep(const float* __restrict__ x, int n, int dim,
-                                                   float* __restrict__ norm,
-                                                   unsigned* __restrict__ stats, int track_max)
+__global__ __launch_bounds__(256) void knn_l2_prep(const float* __restrict__ Q, int nq,
+                                                   const float* __restrict__ T, int nt, int dim,
+                                                   float* __restrict__ qnorm, float* __restrict__ tnorm,
+                                                   unsigned long long* __restrict__ stats, unsigned epoch)
 {
-    const int sub = threadIdx.x & 15;
-    const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
-    const int rl = row < n ? row : n - 1;
-    const float* p = x + static_cast<size_t>(rl) * dim;
-    float s = 0.f;
-    for (int c = sub; c < dim; c += 16) s = fmaf(p[c], p[c], s);
+    __shared__ unsigned wmax[4];
+    __shared__ unsigned wbad[4];
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int qblocks = (nq + 63) / 64;
+    const bool is_t = static_cast<int>(blockIdx.x) >= qblocks;
+    const float* x = is_t ? T : Q;
+    const int n = is_t ? nt : nq;
+    float* norm = is_t ? tnorm : qnorm;
+    const int row0 = (is_t ? blockIdx.x - qblocks : blockIdx.x) * 64;
+    unsigned mx = 0u, bad = 0u;
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
-    if (sub == 0 && row < n) {
-        norm[row] = s;
-        if (!(s < KNN_INF)) atomicOr(&stats[1], 1u);
-        else if (track_max) atomicMax(&stats[0], f32_bits(s));
+    for (int it = 0; it < 4; ++it) {
+        const int row = row0 + it * 16 + grp;
+        const int rl = row < n ? row : n - 1;
+        const float* p = x + static_cast<size_t>(rl) * dim;
+        float s = 0.f;
+        for (int c = sub; c < dim; c += 16) s = fmaf(p[c], p[c], s);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
+        if (sub == 0 && row < n) {
+            norm[row] = s;
+            if (!(s < KNN_INF)) bad = 1u;
+            else if (is_t) mx = max(mx, f32_bits(s));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mx = max(mx, static_cast<unsigned>(__shfl_xor(static_cast<int>(mx), o, 64)));
+        bad |= static_cast<unsigned>(__shfl_xor(static_cast<int>(bad), o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { wmax[threadIdx.x >> 6] = mx; wbad[threadIdx.x >> 6] = bad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+        bad = wbad[0] | wbad[1] | wbad[2] | wbad[3];
+        const unsigned long long tag = static_cast<unsigned long long>(epoch) << 32;
+        if (is_t) atomicMax(&stats[0], tag | mx);
+        if (bad) atomicMax(&stats[1], tag | 1ull);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // coarse pass on the matrix cores
+//
+// Per (query, train row) the accumulator is seeded with -||t||^2/2 and the MFMA chain adds q.t, so
+// it ends as w = q.t - ||t||^2/2 = -(d2a - ||q||^2)/2: the LARGEST w are the nearest rows, and no
+// VALU work is needed to form the ranking value.  The row's position in this lane's stream
+// (lid = tile_in_split*32 + block*16 + reg) is written into the low `bits` mantissa bits of w, so
+// a candidate is ONE float and keeping the 4 largest is branch-free:
+//     n0 = max(x,w0); n1 = med3(x,w0,w1); n2 = med3(x,w1,w2); n3 = med3(x,w2,w3)
+// (5 VALU per pair incl. the bit insert).  The truncation error 2^(bits-23)*|w| is part of the
+// refinement's window (SPEC S1b).  Two accumulator sets: the epilogue of tile t-1 is issued
+// between the MFMAs of tile t, so the matrix pipe does not wait for the selection.
 // ---------------------------------------------------------------------------------------------
-struct Cand4 {
-    float v0, v1, v2, v3;
-    int i0, i1, i2, i3;
+constexpr float KNN_BIG = 3.0e38f;       // finite sentinel: stays finite under the bit insert
+
+__device__ __forceinline__ float embed_lid(float w, unsigned keep_mask, unsigned lid)
+{
+    return __uint_as_float((__float_as_uint(w) & keep_mask) | lid);
+}
+
+__device__ __forceinline__ void top4_insert(f32x4& c, float x)
+{
+    const float n0 = __builtin_amdgcn_fmed3f(x, c[0], KNN_INF);      // = max(x, c0), no canonicalising v_max
+    const float n1 = __builtin_amdgcn_fmed3f(x, c[0], c[1]);
+    const float n2 = __builtin_amdgcn_fmed3f(x, c[1], c[2]);
+    const float n3 = __builtin_amdgcn_fmed3f(x, c[2], c[3]);
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+// NCH = padded dim / 8; FULL = (dim == 8*NCH), which drops the column guards.
+// grid = (ceil(nq/QB), splits).  Dynamic LDS: 2 tiles of TILE_T x (8*NCH + 4) floats (row stride
+// padded by one 16-B slot: conflict-free ds_read_b128 for the 16 rows of a lane group) + 2 x TILE_T
+// seeds (-||t||^2/2, or -KNN_BIG/2 past the last row).
+template <int NCH, bool FULL>
+struct KnnTile {
+    static constexpr int DP = NCH * 8;
+    static constexpr int LDT = DP + 4;
+    static constexpr int F4_PER_ROW = DP / 4;
+    static constexpr int NSTG = TILE_T * F4_PER_ROW / 256;
+    static_assert(TILE_T * F4_PER_ROW % 256 == 0, "tile must split evenly over the workgroup");
+
+    f32x4 stg[NSTG];
+    float stg_n;
+
+    // global -> registers (unconditional loads: clamped addresses, zero-select afterwards)
+    __device__ __forceinline__ void load(const float* __restrict__ T, const float* __restrict__ tnorm, int tile,
+                                         int nt, int dim, int tid)
+    {
+#pragma unroll
+        for (int i = 0; i < NSTG; ++i) {
+            const int f = tid + 256 * i;
+            const int row = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
+            int g = tile * TILE_T + row;
+            g = g < nt ? g : nt - 1;
+            int col = 4 * c4;
+            if (!FULL) col = col < dim ? col : dim - 4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(T + static_cast<size_t>(g) * dim + col);
+            if (!FULL && 4 * c4 >= dim) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            stg[i] = v;
+        }
+        const int gn = tile * TILE_T + (tid & (TILE_T - 1));
+        const float nrm = tnorm[gn < nt ? gn : nt - 1];
+        stg_n = gn < nt ? -0.5f * nrm : -0.5f * KNN_BIG;
+    }
+    // registers -> LDS buffer
+    __device__ __forceinline__ void store(float* __restrict__ Ts, float* __restrict__ Tn, int buf, int tid) const
+    {
+#pragma unroll
+        for (int i = 0; i < NSTG; ++i) {
+            const int f = tid + 256 * i;
+            const int row = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
+            *reinterpret_cast<f32x4*>(Ts + (buf * TILE_T + row) * LDT + 4 * c4) = stg[i];
+        }
+        if (tid < TILE_T) Tn[buf * TILE_T + tid] = stg_n;
+    }
 };
 
-__device__ __forceinline__ void cand_insert(Cand4& c, float s, int j)
+// One tile: seed the accumulators, run the MFMA chain, and (EPI) select the previous tile's
+// accumulators p0/p1 in between.  C[i][j] of lane (j = lane&31), register reg is train row
+// i = (reg&3) + 8*(reg>>2) + 4*(lane>>5) of the 32-row block.
+template <int NCH, bool EPI>
+__device__ __forceinline__ void knn_tile_compute(const float* __restrict__ Ts, const float* __restrict__ Tn,
+                                                 int buf, int r, int h, const f32x4 (&qf)[NCH], f32x16& a0,
+                                                 f32x16& a1, const f32x16& p0, const f32x16& p1, unsigned pbase,
+                                                 unsigned keep_mask, f32x4& cl)
 {
-    if (s < c.v3) {
-        c.v3 = s; c.i3 = j;
-        if (c.v3 < c.v2) { float t = c.v2; c.v2 = c.v3; c.v3 = t; int u = c.i2; c.i2 = c.i3; c.i3 = u; }
-        if (c.v2 < c.v1) { float t = c.v1; c.v1 = c.v2; c.v2 = t; int u = c.i1; c.i1 = c.i2; c.i2 = u; }
-        if (c.v1 < c.v0) { float t = c.v0; c.v0 = c.v1; c.v1 = t; int u = c.i0; c.i0 = c.i1; c.i1 = u; }
+    constexpr int LDT = NCH * 8 + 4;
+    const float* tn = Tn + buf * TILE_T + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 n0 = *reinterpret_cast<const f32x4*>(tn + 8 * g);
+        const f32x4 n1 = *reinterpret_cast<const f32x4*>(tn + 32 + 8 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a0[4 * g + e] = n0[e]; a1[4 * g + e] = n1[e]; }
+    }
+    const float* tb = Ts + buf * TILE_T * LDT + r * LDT + 4 * h;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(tb + 8 * c);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(tb + 32 * LDT + 8 * c);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[t], qf[c][t], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[t], qf[c][t], a1, 0, 0, 0);
+        }
+        if (EPI) {
+            constexpr int PER = 32 / NCH;          // selection steps per chunk
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int v = c * PER + u;         // 0..31: block v>>4, register v&15
+                const float w = v < 16 ? p0[v & 15] : p1[v & 15];
+                top4_insert(cl, embed_lid(w, keep_mask, pbase | static_cast<unsigned>(v)));
+            }
+            // pin the selection to this chunk: without a use here hipcc sinks all of it below the
+            // MFMA chain (in front of the barrier), where nothing hides it.  Placed after the
+            // chunk's MFMAs, the ~10 VALU ops issue in the shadow of the last 64-cycle MFMA.
+            asm volatile("" : "+v"(cl[0]), "+v"(cl[1]), "+v"(cl[2]), "+v"(cl[3]));
+        }
     }
 }
 
-// NCH = padded dim / 8.  grid = (ceil(nq/QB), splits).  Dynamic LDS: 2 tiles of
-// TILE_T x (8*NCH + 4) floats (row stride padded by one 16-B slot: conflict-free ds_read_b128 for
-// the 16 rows of a lane group) + 2 x TILE_T train norms.
-template <int NCH>
+__device__ __forceinline__ void knn_select_all(const f32x16& p0, const f32x16& p1, unsigned pbase,
+                                               unsigned keep_mask, f32x4& cl)
+{
+#pragma unroll
+    for (int v = 0; v < 32; ++v) {
+        const float w = v < 16 ? p0[v & 15] : p1[v & 15];
+        top4_insert(cl, embed_lid(w, keep_mask, pbase | static_cast<unsigned>(v)));
+    }
+}
+
+template <int NCH, bool FULL>
 __global__ __launch_bounds__(256, 2) void knn_l2_mfma(
     const float* __restrict__ Q, const float* __restrict__ T, const float* __restrict__ tnorm, int nq,
-    int nt, int dim, int tiles_per_split, float* __restrict__ cand_val, int* __restrict__ cand_idx,
-    int slots)
+    int nt, int dim, int tiles_per_split, unsigned keep_mask, float* __restrict__ cand_val, int slots)
 {
-    constexpr int DP = NCH * 8;
-    constexpr int LDT = DP + 4;
-    constexpr int F4_PER_ROW = DP / 4;
-    constexpr int NSTG = TILE_T * F4_PER_ROW / 256;
-    static_assert(TILE_T * F4_PER_ROW % 256 == 0, "tile must split evenly over the workgroup");
-
+    using Tile = KnnTile<NCH, FULL>;
+    constexpr int LDT = Tile::LDT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ts = smem;                          // [2][TILE_T][LDT]
     float* Tn = smem + 2 * TILE_T * LDT;       // [2][TILE_T]
@@ -171,13 +307,16 @@ __global__ __launch_bounds__(256, 2) void knn_l2_mfma(
     const int qld = qrow < nq ? qrow : nq - 1;
 
     // B operand: this lane's query row, k = 8c + 4h + {0..3} for chunk c (the k permutation is
-    // shared with the A operand below, and a dot product does not care about k order).
+    // shared with the A operand, and a dot product does not care about k order).
     f32x4 qf[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int k0 = 8 * c + 4 * h;
-        qf[c] = k0 < dim ? *reinterpret_cast<const f32x4*>(Q + static_cast<size_t>(qld) * dim + k0)
-                         : f32x4{0.f, 0.f, 0.f, 0.f};
+        int col = k0;
+        if (!FULL) col = col < dim ? col : dim - 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(Q + static_cast<size_t>(qld) * dim + col);
+        if (!FULL && k0 >= dim) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        qf[c] = v;
     }
 
     const int ntiles = (nt + TILE_T - 1) / TILE_T;
@@ -185,93 +324,53 @@ __global__ __launch_bounds__(256, 2) void knn_l2_mfma(
     int tile1 = tile0 + tiles_per_split;
     if (tile1 > ntiles) tile1 = ntiles;
 
-    Cand4 cl{KNN_INF, KNN_INF, KNN_INF, KNN_INF, -1, -1, -1, -1};
-
-    f32x4 stg[NSTG];
-    float stg_n = 0.f;
-    auto stage_load = [&](int tile) {
-#pragma unroll
-        for (int i = 0; i < NSTG; ++i) {
-            const int f = tid + 256 * i;
-            const int row = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
-            int g = tile * TILE_T + row;
-            g = g < nt ? g : nt - 1;
-            stg[i] = 4 * c4 < dim
-                         ? *reinterpret_cast<const f32x4*>(T + static_cast<size_t>(g) * dim + 4 * c4)
-                         : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        if (tid < TILE_T) {
-            int g = tile * TILE_T + tid;
-            stg_n = tnorm[g < nt ? g : nt - 1];
-        }
-    };
-    auto stage_store = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NSTG; ++i) {
-            const int f = tid + 256 * i;
-            const int row = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
-            *reinterpret_cast<f32x4*>(Ts + (buf * TILE_T + row) * LDT + 4 * c4) = stg[i];
-        }
-        if (tid < TILE_T) Tn[buf * TILE_T + tid] = stg_n;
-    };
-
-    if (tile0 < tile1) {
-        stage_load(tile0);
-        stage_store(0);
-    }
-    __syncthreads();
-
-    for (int tile = tile0; tile < tile1; ++tile) {
-        const int buf = (tile - tile0) & 1;
-        const bool more = tile + 1 < tile1;
-        if (more) stage_load(tile + 1);          // global loads fly under the MFMA chain
-
-        f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        f32x16 acc1 = acc0;
-        const float* tb = Ts + buf * TILE_T * LDT + r * LDT + 4 * h;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(tb + 8 * c);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(tb + 32 * LDT + 8 * c);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], qf[c][t], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], qf[c][t], acc1, 0, 0, 0);
-            }
-        }
-
-        // epilogue: C[i][j] sits in lane (j = lane&31), register reg with
-        // i = (reg&3) + 8*(reg>>2) + 4*(lane>>5): 16 train rows per block for this lane's query.
-        const float* tn = Tn + buf * TILE_T + 4 * h;
-        const int jbase = tile * TILE_T + 4 * h;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 n0 = *reinterpret_cast<const f32x4*>(tn + 8 * g);
-            const f32x4 n1 = *reinterpret_cast<const f32x4*>(tn + 32 + 8 * g);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int j0 = jbase + 8 * g + e;
-                float s0 = fmaf(-2.f, acc0[4 * g + e], n0[e]);
-                s0 = j0 < nt ? s0 : KNN_INF;
-                cand_insert(cl, s0, j0);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int j1 = jbase + 32 + 8 * g + e;
-                float s1 = fmaf(-2.f, acc1[4 * g + e], n1[e]);
-                s1 = j1 < nt ? s1 : KNN_INF;
-                cand_insert(cl, s1, j1);
-            }
-        }
-
-        if (more) stage_store(buf ^ 1);
+    f32x4 cl = {-KNN_BIG, -KNN_BIG, -KNN_BIG, -KNN_BIG};
+    if (tile0 < tile1) {                       // block-uniform
+        Tile st;
+        st.load(T, tnorm, tile0, nt, dim, tid);
+        st.store(Ts, Tn, 0, tid);
         __syncthreads();
+
+        // every accumulator has a compile-time name: tiles alternate A, B, A, ...
+        f32x16 accA0, accA1, accB0, accB1;
+        int tile = tile0;
+        {   // first tile -> A, nothing pending
+            const bool more = tile + 1 < tile1;
+            if (more) st.load(T, tnorm, tile + 1, nt, dim, tid);
+            knn_tile_compute<NCH, false>(Ts, Tn, 0, r, h, qf, accA0, accA1, accA0, accA1, 0u, keep_mask, cl);
+            if (more) st.store(Ts, Tn, 1, tid);
+            __syncthreads();
+            ++tile;
+        }
+        for (;;) {
+            if (tile >= tile1) { knn_select_all(accA0, accA1, static_cast<unsigned>(tile - 1 - tile0) << 5, keep_mask, cl); break; }
+            {   // tile -> B while selecting A (tile-1)
+                const int buf = (tile - tile0) & 1;
+                const bool more = tile + 1 < tile1;
+                if (more) st.load(T, tnorm, tile + 1, nt, dim, tid);
+                knn_tile_compute<NCH, true>(Ts, Tn, buf, r, h, qf, accB0, accB1, accA0, accA1,
+                                            static_cast<unsigned>(tile - 1 - tile0) << 5, keep_mask, cl);
+                if (more) st.store(Ts, Tn, buf ^ 1, tid);
+                __syncthreads();
+                ++tile;
+            }
+            if (tile >= tile1) { knn_select_all(accB0, accB1, static_cast<unsigned>(tile - 1 - tile0) << 5, keep_mask, cl); break; }
+            {   // tile -> A while selecting B (tile-1)
+                const int buf = (tile - tile0) & 1;
+                const bool more = tile + 1 < tile1;
+                if (more) st.load(T, tnorm, tile + 1, nt, dim, tid);
+                knn_tile_compute<NCH, true>(Ts, Tn, buf, r, h, qf, accA0, accA1, accB0, accB1,
+                                            static_cast<unsigned>(tile - 1 - tile0) << 5, keep_mask, cl);
+                if (more) st.store(Ts, Tn, buf ^ 1, tid);
+                __syncthreads();
+                ++tile;
+            }
+        }
     }
 
     if (qrow < nq) {
         const size_t o = static_cast<size_t>(qrow) * slots + (blockIdx.y * 2 + h) * KNN_C;
-        *reinterpret_cast<f32x4*>(cand_val + o) = f32x4{cl.v0, cl.v1, cl.v2, cl.v3};
-        *reinterpret_cast<int4*>(cand_idx + o) = int4{cl.i0, cl.i1, cl.i2, cl.i3};
+        *reinterpret_cast<f32x4*>(cand_val + o) = cl;
     }
 }
 
@@ -294,23 +393,38 @@ __device__ __forceinline__ void best2_insert(Best2& b, uint64_t key, float d)
 template <bool VEC4>
 __global__ __launch_bounds__(256) void knn_l2_refine(
     const float* __restrict__ Q, const float* __restrict__ T, const float* __restrict__ qnorm,
-    unsigned* __restrict__ stats, int nq, int nt, int dim, int k, int slots,
-    const float* __restrict__ cand_val, const int* __restrict__ cand_idx, float eps_coef,
-    pm_match* __restrict__ out)
+    const unsigned long long* __restrict__ stats, unsigned epoch, unsigned* __restrict__ diag, int nq, int nt,
+    int dim, int k, int slots, const float* __restrict__ cand_val, int tiles_per_split, unsigned lid_mask,
+    float eps_coef, float embed_coef, pm_match* __restrict__ out)
 {
     const int lane = threadIdx.x & 63;
     const int q = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (q >= nq) return;
     const float* qp = Q + static_cast<size_t>(q) * dim;
     const float na = qnorm[q];
-    const float tmax = __uint_as_float(stats[0]);
-    const bool nonfinite = stats[1] != 0u;
-    const float eps = eps_coef * (na + tmax);
+    const unsigned long long s0 = stats[0], s1 = stats[1];
+    const float tmax = static_cast<unsigned>(s0 >> 32) == epoch ? __uint_as_float(static_cast<unsigned>(s0)) : 0.f;
+    const bool nonfinite = static_cast<unsigned>(s1 >> 32) == epoch && (s1 & 1ull);
+    // window half-width: fp error of the coarse value + truncation by the embedded row id
+    const float eps = eps_coef * (na + tmax) + embed_coef * (na + 2.f * tmax);
+    const float* cv = cand_val + static_cast<size_t>(q) * slots;
+    // slot value w = q.t - ||t||^2/2 (+id bits)  ->  coarse squared distance d2a = ||q||^2 - 2w
+    auto coarse = [&](int s) -> float {
+        const float w = cv[s];
+        return w > -1.0e38f ? fmaf(-2.f, w, na) : KNN_INF;
+    };
+    auto row_of = [&](int s) -> int {
+        const unsigned lid = __float_as_uint(cv[s]) & lid_mask;
+        const int split = s / (2 * KNN_C), hh = (s / KNN_C) & 1;
+        const int reg = lid & 15, blk = (lid >> 4) & 1;
+        return (split * tiles_per_split + static_cast<int>(lid >> 5)) * TILE_T + 32 * blk + (reg & 3) +
+               8 * (reg >> 2) + 4 * hh;
+    };
 
     // k-th smallest coarse value over all slots (k <= 2)
     float m0 = KNN_INF, m1 = KNN_INF;
     for (int s = lane; s < slots; s += 64) {
-        const float v = cand_val[static_cast<size_t>(q) * slots + s];
+        const float v = coarse(s);
         if (v < m1) { if (v < m0) { m1 = m0; m0 = v; } else { m1 = v; } }
     }
     float tau = KNN_INF;
@@ -321,24 +435,21 @@ __global__ __launch_bounds__(256) void knn_l2_refine(
         const int first = __ffsll(static_cast<long long>(owners)) - 1;
         if (lane == first) { m0 = m1; m1 = KNN_INF; }
     }
-    const float thr = ((tau + na) + eps) * 1.00000095367431640625f + eps;
+    const float thr = (tau + eps) * 1.00000095367431640625f + eps;
 
     // a sub-list whose largest kept entry is inside the window may have dropped candidates
     bool spill = false;
     for (int s = lane; s < slots; s += 64)
-        if ((s & (KNN_C - 1)) == KNN_C - 1) {
-            const float v = cand_val[static_cast<size_t>(q) * slots + s];
-            spill |= (v + na) <= thr;
-        }
+        if ((s & (KNN_C - 1)) == KNN_C - 1) spill |= coarse(s) <= thr;
     const bool rescan = nonfinite || !(thr < KNN_INF) || __any(spill);
-    if (rescan && lane == 0) atomicAdd(&stats[2], 1u);
+    if (diag && lane == 0) { if (rescan) atomicAdd(&diag[0], 1u); if (nonfinite) diag[1] = 1u; }
 
     Best2 b{~0ull, ~0ull, KNN_INF, KNN_INF};
     if (!rescan) {
         for (int s = lane; s < slots; s += 64) {
-            const float v = cand_val[static_cast<size_t>(q) * slots + s];
-            const int j = cand_idx[static_cast<size_t>(q) * slots + s];
-            if (j >= 0 && (v + na) <= thr) {
+            const float v = coarse(s);
+            const int j = row_of(s);
+            if (v <= thr && j < nt) {
                 const float d = __builtin_sqrtf(
                     l2sqr_canonical<VEC4>(qp, T + static_cast<size_t>(j) * dim, dim));
                 best2_insert(b, knn_key(d, j), d);
@@ -560,22 +671,22 @@ __global__ __launch_bounds__(256) void knn_l2_exact(const float* __restrict__ Q,
     }
 }
 
-template <int NCH>
+template <int NCH, bool FULL>
 int launch_mfma(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt, int dim,
-                const float* tnorm, int splits, int tiles_per_split, float* cval, int* cidx, int slots)
+                const float* tnorm, int splits, int tiles_per_split, unsigned keep_mask, float* cval, int slots)
 {
     constexpr int LDT = NCH * 8 + 4;
     const size_t lds = (2 * TILE_T * LDT + 2 * TILE_T) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        PM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_l2_mfma<NCH>),
+        PM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_l2_mfma<NCH, FULL>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
         attr_done = true;
     }
     dim3 grid((nq + QB - 1) / QB, splits);
     pm::ScopedKernelTime t(ctx, "knn_l2_mfma");
-    hipLaunchKernelGGL(knn_l2_mfma<NCH>, grid, dim3(256), lds, ctx->stream, dq, dt, tnorm, nq, nt, dim,
-                       tiles_per_split, cval, cidx, slots);
+    hipLaunchKernelGGL((knn_l2_mfma<NCH, FULL>), grid, dim3(256), lds, ctx->stream, dq, dt, tnorm, nq, nt, dim,
+                       tiles_per_split, keep_mask, cval, slots);
     PM_HIP_CHECK(hipGetLastError());
     return PM_OK;
 }
@@ -609,7 +720,7 @@ extern "C" int pm_bf_knn_l2_f32_dev(pm_ctx* ctx, const float* dq, int nq, const 
     PM_HIP_CHECK(hipSetDevice(ctx->device));
 
     const bool fast = !(flags & PM_KNN_FORCE_EXACT) && k <= 2 && (dim % 4) == 0 && dim <= 128 && nt >= 1;
-    if (!fast) { ctx->last_knn_stats = nullptr; return run_exact(ctx, dq, nq, dt, nt, dim, k, dout); }
+    if (!fast) return run_exact(ctx, dq, nq, dt, nt, dim, k, dout);
 
     // split the train rows so that the grid fills the chip (~2 workgroups per CU)
     const int ntiles = (nt + TILE_T - 1) / TILE_T;
@@ -621,40 +732,61 @@ extern "C" int pm_bf_knn_l2_f32_dev(pm_ctx* ctx, const float* dq, int nq, const 
     const int tiles_per_split = (ntiles + splits - 1) / splits;
     splits = (ntiles + tiles_per_split - 1) / tiles_per_split;
     const int slots = splits * 2 * KNN_C;
+    // row id inside a lane's stream: tile_in_split*32 + block*16 + reg, in the low mantissa bits
+    int lid_bits = 5;
+    while ((1 << lid_bits) < tiles_per_split * 32) ++lid_bits;
+    if (lid_bits > 16) return run_exact(ctx, dq, nq, dt, nt, dim, k, dout);     // > 2048 tiles per split
+    const unsigned lid_mask = (1u << lid_bits) - 1u;
 
     // scratch: norms, stats, candidate lists.  The arena is carved per call; callers that
     // interleave calls on one context are serialised by the stream.
-    const size_t need = pm::align_up(sizeof(float) * nq, 256) + pm::align_up(sizeof(float) * nt, 256) + 256 +
-                        2 * pm::align_up(sizeof(float) * static_cast<size_t>(nq) * slots, 256) + 1024;
+    const size_t need = pm::align_up(sizeof(float) * nq, 256) + pm::align_up(sizeof(float) * nt, 256) +
+                        pm::align_up(sizeof(float) * static_cast<size_t>(nq) * slots, 256) + 1024;
     int rc = pm::arena_reserve(ctx, need);
     if (rc != PM_OK) return rc;
     pm::arena_reset(ctx);
     float* qnorm = static_cast<float*>(pm::arena_take(ctx, sizeof(float) * nq));
     float* tnorm = static_cast<float*>(pm::arena_take(ctx, sizeof(float) * nt));
-    unsigned* stats = static_cast<unsigned*>(pm::arena_take(ctx, 16));
     float* cval = static_cast<float*>(pm::arena_take(ctx, sizeof(float) * static_cast<size_t>(nq) * slots));
-    int* cidx = static_cast<int*>(pm::arena_take(ctx, sizeof(int) * static_cast<size_t>(nq) * slots));
-    PM_REQUIRE(qnorm && tnorm && stats && cval && cidx, PM_E_NOMEM, "scratch arena too small");
+    PM_REQUIRE(qnorm && tnorm && cval, PM_E_NOMEM, "scratch arena too small");
 
-    PM_HIP_CHECK(hipMemsetAsync(stats, 0, 16, ctx->stream));
-    ctx->last_knn_stats = stats;
+    unsigned long long* stats = ctx->knn_stats;          // persistent, epoch-tagged: never cleared
+    if (++ctx->knn_epoch == 0u) {              // 2^32 calls: restart the epoch tags
+        PM_HIP_CHECK(hipMemsetAsync(stats, 0, 16, ctx->stream));
+        ctx->knn_epoch = 1u;
+    }
+    const unsigned epoch = ctx->knn_epoch;
+    unsigned* diag = nullptr;
+    if (ctx->knn_diag) {
+        diag = ctx->knn_diag_words;
+        PM_HIP_CHECK(hipMemsetAsync(diag, 0, 8, ctx->stream));
+    }
     {
         pm::ScopedKernelTime t(ctx, "knn_l2_prep");
-        hipLaunchKernelGGL(knn_l2_prep, dim3((nq + 15) / 16), dim3(256), 0, ctx->stream, dq, nq, dim, qnorm, stats, 0);
-        hipLaunchKernelGGL(knn_l2_prep, dim3((nt + 15) / 16), dim3(256), 0, ctx->stream, dt, nt, dim, tnorm, stats, 1);
+        hipLaunchKernelGGL(knn_l2_prep, dim3((nq + 63) / 64 + (nt + 63) / 64), dim3(256), 0, ctx->stream, dq, nq, dt,
+                           nt, dim, qnorm, tnorm, stats, epoch);
         PM_HIP_CHECK(hipGetLastError());
     }
-    if (dim <= 32) rc = launch_mfma<4>(ctx, dq, nq, dt, nt, dim, tnorm, splits, tiles_per_split, cval, cidx, slots);
-    else if (dim <= 64) rc = launch_mfma<8>(ctx, dq, nq, dt, nt, dim, tnorm, splits, tiles_per_split, cval, cidx, slots);
-    else rc = launch_mfma<16>(ctx, dq, nq, dt, nt, dim, tnorm, splits, tiles_per_split, cval, cidx, slots);
+#define PM_LAUNCH_MFMA(NCH_, FULL_) \
+    launch_mfma<NCH_, FULL_>(ctx, dq, nq, dt, nt, dim, tnorm, splits, tiles_per_split, ~lid_mask, cval, slots)
+    if (dim == 128) rc = PM_LAUNCH_MFMA(16, true);
+    else if (dim == 64) rc = PM_LAUNCH_MFMA(8, true);
+    else if (dim == 32) rc = PM_LAUNCH_MFMA(4, true);
+    else if (dim < 32) rc = PM_LAUNCH_MFMA(4, false);
+    else if (dim < 64) rc = PM_LAUNCH_MFMA(8, false);
+    else rc = PM_LAUNCH_MFMA(16, false);
+#undef PM_LAUNCH_MFMA
     if (rc != PM_OK) return rc;
 
-    // |coarse - canonical| <= (4*dim + 16) * 2^-24 * (||q||^2 + ||t||^2); see docs/SPEC.md S1b
-    const float eps_coef = static_cast<float>((4.0 * dim + 16.0) * 5.9604644775390625e-8 * 1.001);
+    // |coarse - canonical| <= (6*dim + 32) * 2^-24 * (||q||^2 + ||t||^2) + 2^(bits-23) * (||q||^2 + 2||t||^2);
+    // see docs/SPEC.md S1b
+    const float eps_coef = static_cast<float>((6.0 * dim + 32.0) * 5.9604644775390625e-8 * 1.001);
+    const float embed_coef = static_cast<float>(static_cast<double>(1u << lid_bits) * 1.1920928955078125e-7 * 1.01);
     {
         pm::ScopedKernelTime t(ctx, "knn_l2_refine");
         hipLaunchKernelGGL(knn_l2_refine<true>, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, dq, dt, qnorm, stats,
-                           nq, nt, dim, k, slots, cval, cidx, eps_coef, dout);
+                           epoch, diag, nq, nt, dim, k, slots, cval, tiles_per_split, lid_mask, eps_coef, embed_coef,
+                           dout);
         PM_HIP_CHECK(hipGetLastError());
     }
     return PM_OK;

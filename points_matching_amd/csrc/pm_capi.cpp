@@ -25,7 +25,6 @@ int arena_reserve(pm_ctx* ctx, size_t bytes)
     PM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (ctx->arena) PM_HIP_CHECK(hipFree(ctx->arena));
     ctx->arena = nullptr;
-    ctx->last_knn_stats = nullptr;
     ctx->arena_cap = 0;
     size_t cap = align_up(bytes + bytes / 4, size_t(1) << 20);
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&ctx->arena), cap);
@@ -145,6 +144,15 @@ int pm_ctx_create(int device, pm_ctx** out)
         return PM_E_HIP;
     }
     c->stream = c->own_stream;
+    e = hipMalloc(reinterpret_cast<void**>(&c->knn_stats), 64);
+    if (e == hipSuccess) e = hipMemset(c->knn_stats, 0, 64);
+    if (e != hipSuccess) {
+        set_error("hipMalloc failed: %s", hipGetErrorString(e));
+        (void)hipStreamDestroy(c->own_stream);
+        delete c;
+        return PM_E_NOMEM;
+    }
+    c->knn_diag_words = reinterpret_cast<unsigned*>(c->knn_stats + 4);
     *out = c;
     return PM_OK;
 }
@@ -157,6 +165,7 @@ int pm_ctx_destroy(pm_ctx* ctx)
     drain_timers(ctx);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->knn_stats) (void)hipFree(ctx->knn_stats);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -211,15 +220,20 @@ int pm_ctx_timing_get(pm_ctx* ctx, const char* kernel, double* mean_ms, int* lau
     return PM_OK;
 }
 
+int pm_ctx_knn_diag_enable(pm_ctx* ctx, int enable)
+{
+    PM_REQUIRE(ctx != nullptr, PM_E_INVALID, "ctx is null");
+    ctx->knn_diag = enable != 0;
+    return PM_OK;
+}
+
 int pm_ctx_knn_stats(pm_ctx* ctx, int* rescans, int* nonfinite)
 {
     PM_REQUIRE(ctx != nullptr, PM_E_INVALID, "ctx is null");
-    unsigned h[4] = {0, 0, 0, 0};
-    if (ctx->last_knn_stats) {
-        PM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        PM_HIP_CHECK(hipMemcpy(h, ctx->last_knn_stats, sizeof h, hipMemcpyDeviceToHost));
-    }
-    if (rescans) *rescans = static_cast<int>(h[2]);
+    unsigned h[2] = {0, 0};
+    PM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    PM_HIP_CHECK(hipMemcpy(h, ctx->knn_diag_words, sizeof h, hipMemcpyDeviceToHost));
+    if (rescans) *rescans = static_cast<int>(h[0]);
     if (nonfinite) *nonfinite = static_cast<int>(h[1]);
     return PM_OK;
 }

@@ -59,7 +59,12 @@ struct pm_ctx {
     std::map<std::string, pm::KernelTimer> timers;
     std::vector<hipEvent_t> event_pool;
     int n_cu = 256;
-    unsigned* last_knn_stats = nullptr;   // device, 4 words, inside the arena
+    // kNN side-band: [0..1] epoch-tagged 64-bit maxima (never cleared), diag words (re-scan count,
+    // non-finite flag) filled only while knn_diag is on
+    unsigned long long* knn_stats = nullptr;
+    unsigned* knn_diag_words = nullptr;
+    unsigned knn_epoch = 0;
+    bool knn_diag = false;
 };
 
 namespace pm {

@@ -270,12 +270,19 @@ __device__ __forceinline__ int resolve_n(int n_max, const int* __restrict__ d_n)
     return v < n_max ? (v < 0 ? 0 : v) : n_max;
 }
 
+// Scratch of one shard: fp32 models for the scorer, fp64 models for a local finalisation,
+// inlier counters.  The solve kernel also clears the counters and the shard key, so the run
+// needs no memset nodes.
 __global__ __launch_bounds__(64) void ransac_solve(const float* __restrict__ xy1, const float* __restrict__ xy2,
                                                    int n_max, const int* __restrict__ d_n, uint64_t seed,
-                                                   int64_t hyp_begin, int nh, float* __restrict__ models)
+                                                   int64_t hyp_begin, int nh, float* __restrict__ models,
+                                                   double* __restrict__ models64, int* __restrict__ counts,
+                                                   unsigned long long* __restrict__ key)
 {
     const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t == 0) *key = 0ull;
     if (t >= nh) return;
+    counts[t] = 0;
     const int n = resolve_n(n_max, d_n);
     float* m = models + static_cast<size_t>(t) * MODEL_STRIDE;
     if (n < 8) { m[9] = 0.f; return; }
@@ -284,6 +291,9 @@ __global__ __launch_bounds__(64) void ransac_solve(const float* __restrict__ xy1
 #pragma unroll
     for (int i = 0; i < 9; ++i) m[i] = static_cast<float>(F[i]);
     m[9] = ok ? 1.f : 0.f;
+    double* m64 = models64 + static_cast<size_t>(t) * 9;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) m64[i] = F[i];
 }
 
 template <int KIND>
@@ -311,22 +321,35 @@ __global__ __launch_bounds__(256) void ransac_score(const float* __restrict__ xy
     if (t < nh && cnt) atomicAdd(&counts[t], cnt);
 }
 
-__global__ __launch_bounds__(256) void ransac_select(const float* __restrict__ models, const int* __restrict__ counts,
-                                                     int nh, int64_t hyp_begin, unsigned long long* __restrict__ best)
+__device__ __forceinline__ unsigned long long hyp_key(const float* __restrict__ models, const int* __restrict__ counts,
+                                                      int t, int64_t hyp_begin)
 {
-    __shared__ unsigned long long wbest[4];
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    unsigned long long key = 0ull;
-    if (t < nh && models[static_cast<size_t>(t) * MODEL_STRIDE + 9] != 0.f) {
-        const uint32_t h = static_cast<uint32_t>(hyp_begin + t);
-        key = (static_cast<unsigned long long>(static_cast<uint32_t>(counts[t])) << 32) |
-              static_cast<unsigned long long>(0xFFFFFFFFu - h);
-    }
+    const float valid = models[static_cast<size_t>(t) * MODEL_STRIDE + 9];   // both loads unconditional
+    const uint32_t cnt = static_cast<uint32_t>(counts[t]);
+    const uint32_t h = static_cast<uint32_t>(hyp_begin + t);
+    const unsigned long long key = (static_cast<unsigned long long>(cnt) << 32) |
+                                   static_cast<unsigned long long>(0xFFFFFFFFu - h);
+    return valid != 0.f ? key : 0ull;
+}
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long key)
+{
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const unsigned long long w = __shfl_xor(key, o, 64);
         key = w > key ? w : key;
     }
+    return key;
+}
+
+// shard key only (multi-GPU: the caller all-reduces it)
+__global__ __launch_bounds__(256) void ransac_select(const float* __restrict__ models, const int* __restrict__ counts,
+                                                     int nh, int64_t hyp_begin, unsigned long long* __restrict__ best)
+{
+    __shared__ unsigned long long wbest[4];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    unsigned long long key = t < nh ? hyp_key(models, counts, t, hyp_begin) : 0ull;
+    key = wave_max_u64(key);
     if ((threadIdx.x & 63) == 0) wbest[threadIdx.x >> 6] = key;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -336,7 +359,7 @@ __global__ __launch_bounds__(256) void ransac_select(const float* __restrict__ m
     }
 }
 
-// result block in device memory: 9 doubles F, then int32 valid, int32 n_inliers
+// result block in device memory
 struct FinalOut {
     double F[9];
     int valid;
@@ -345,10 +368,62 @@ struct FinalOut {
     int pad;
 };
 
+__device__ __forceinline__ void publish_model(FinalOut* __restrict__ fo, double* __restrict__ F_out,
+                                              int* __restrict__ n_out, const double (&F)[9], bool ok)
+{
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const double v = ok ? F[i] : 0.0;
+        fo->F[i] = v;
+        fo->F32[i] = static_cast<float>(v);
+        if (F_out) F_out[i] = v;
+    }
+    fo->valid = ok ? 1 : 0;
+    fo->n_inliers = 0;
+    if (n_out) *n_out = 0;
+}
+
+// single-shard run: pick the winner of THIS shard and publish its stored fp64 model (no second
+// solve).  One workgroup of 1024 threads strides over the shard.
+__global__ __launch_bounds__(1024) void ransac_pick(const float* __restrict__ models,
+                                                    const double* __restrict__ models64,
+                                                    const int* __restrict__ counts, int nh, int64_t hyp_begin,
+                                                    unsigned long long* __restrict__ best, FinalOut* __restrict__ fo,
+                                                    double* __restrict__ F_out, int* __restrict__ n_out)
+{
+    __shared__ unsigned long long wbest[16];
+    unsigned long long key = 0ull;
+    for (int t0 = threadIdx.x; t0 < nh; t0 += 4 * 1024) {
+        unsigned long long k4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + u * 1024;
+            k4[u] = hyp_key(models, counts, t < nh ? t : nh - 1, hyp_begin);   // clamped: a duplicate is harmless
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) key = k4[u] > key ? k4[u] : key;
+    }
+    key = wave_max_u64(key);
+    if ((threadIdx.x & 63) == 0) wbest[threadIdx.x >> 6] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) key = wbest[w] > key ? wbest[w] : key;
+        *best = key;
+        double F[9];
+        const bool ok = key != 0ull;
+        const int t = ok ? static_cast<int>(static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(key)) - hyp_begin) : 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) F[i] = ok ? models64[static_cast<size_t>(t) * 9 + i] : 0.0;
+        publish_model(fo, F_out, n_out, F, ok);
+    }
+}
+
+// any-shard finalisation: re-derive the model of the id inside *key from (seed, id)
 __global__ __launch_bounds__(64) void ransac_final_solve(const float* __restrict__ xy1, const float* __restrict__ xy2,
                                                          int n_max, const int* __restrict__ d_n, uint64_t seed,
                                                          const unsigned long long* __restrict__ key,
-                                                         FinalOut* __restrict__ fo)
+                                                         FinalOut* __restrict__ fo, double* __restrict__ F_out,
+                                                         int* __restrict__ n_out)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int n = resolve_n(n_max, d_n);
@@ -361,16 +436,14 @@ __global__ __launch_bounds__(64) void ransac_final_solve(const float* __restrict
         const uint32_t h = 0xFFFFFFFFu - static_cast<uint32_t>(k);
         ok = hyp_model(xy1, xy2, n, seed, static_cast<uint64_t>(h), F);
     }
-#pragma unroll
-    for (int i = 0; i < 9; ++i) { fo->F[i] = ok ? F[i] : 0.0; fo->F32[i] = ok ? static_cast<float>(F[i]) : 0.f; }
-    fo->valid = ok ? 1 : 0;
-    fo->n_inliers = 0;
+    publish_model(fo, F_out, n_out, F, ok);
 }
 
 template <int KIND>
 __global__ __launch_bounds__(256) void ransac_final_mask(const float* __restrict__ xy1, const float* __restrict__ xy2,
                                                          int n_max, const int* __restrict__ d_n, float thr2,
-                                                         FinalOut* __restrict__ fo, uint8_t* __restrict__ mask)
+                                                         FinalOut* __restrict__ fo, uint8_t* __restrict__ mask,
+                                                         int* __restrict__ n_out)
 {
     const int n = resolve_n(n_max, d_n);
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -385,7 +458,7 @@ __global__ __launch_bounds__(256) void ransac_final_mask(const float* __restrict
     }
     if (i < n_max) mask[i] = in ? 1 : 0;
     const unsigned long long b = __ballot(in);
-    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&fo->n_inliers, __popcll(b));
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_out ? n_out : &fo->n_inliers, __popcll(b));
 }
 
 int check_params(const pm_ransac_params* p)
@@ -399,20 +472,44 @@ int check_params(const pm_ransac_params* p)
     return PM_OK;
 }
 
-// score the shard; arena must already hold room.  d_key is zeroed here.
+struct ShardScratch {
+    float* models;
+    double* models64;
+    int* counts;
+    FinalOut* fo;
+};
+
+size_t shard_scratch_bytes(const pm_ransac_params* p)
+{
+    const size_t nh = static_cast<size_t>(p->hyp_end - p->hyp_begin);
+    return pm::align_up(sizeof(float) * MODEL_STRIDE * nh, 256) + pm::align_up(sizeof(double) * 9 * nh, 256) +
+           pm::align_up(sizeof(int) * nh, 256) + 512;
+}
+
+int take_scratch(pm_ctx* ctx, const pm_ransac_params* p, ShardScratch& sc)
+{
+    const size_t nh = static_cast<size_t>(p->hyp_end - p->hyp_begin);
+    sc.models = static_cast<float*>(pm::arena_take(ctx, sizeof(float) * MODEL_STRIDE * nh + 16));
+    sc.models64 = static_cast<double*>(pm::arena_take(ctx, sizeof(double) * 9 * nh + 16));
+    sc.counts = static_cast<int*>(pm::arena_take(ctx, sizeof(int) * nh + 16));
+    sc.fo = static_cast<FinalOut*>(pm::arena_take(ctx, sizeof(FinalOut)));
+    PM_REQUIRE(sc.models && sc.models64 && sc.counts && sc.fo, PM_E_NOMEM, "scratch arena too small");
+    return PM_OK;
+}
+
+// solve + score the shard.  On return (stream order) counts[] hold the inlier counts.
 int score_shard(pm_ctx* ctx, const float* dxy1, const float* dxy2, int n, const int* d_n,
-                const pm_ransac_params* p, unsigned long long* d_key, char* scratch)
+                const pm_ransac_params* p, unsigned long long* d_key, const ShardScratch& sc)
 {
     const int nh = static_cast<int>(p->hyp_end - p->hyp_begin);
-    PM_HIP_CHECK(hipMemsetAsync(d_key, 0, sizeof(unsigned long long), ctx->stream));
-    if (nh == 0) return PM_OK;
-    float* models = reinterpret_cast<float*>(scratch);
-    int* counts = reinterpret_cast<int*>(scratch + pm::align_up(sizeof(float) * MODEL_STRIDE * nh, 256));
-    PM_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(int) * nh, ctx->stream));
+    if (nh == 0) {
+        PM_HIP_CHECK(hipMemsetAsync(d_key, 0, sizeof(unsigned long long), ctx->stream));
+        return PM_OK;
+    }
     {
         pm::ScopedKernelTime t(ctx, "ransac_solve");
         hipLaunchKernelGGL(ransac_solve, dim3((nh + 63) / 64), dim3(64), 0, ctx->stream, dxy1, dxy2, n, d_n, p->seed,
-                           p->hyp_begin, nh, models);
+                           p->hyp_begin, nh, sc.models, sc.models64, sc.counts, d_key);
         PM_HIP_CHECK(hipGetLastError());
     }
     const int hb = (nh + 255) / 256;
@@ -428,44 +525,64 @@ int score_shard(pm_ctx* ctx, const float* dxy1, const float* dxy2, int n, const 
         pm::ScopedKernelTime t(ctx, "ransac_score");
         if (p->error_kind == PM_ERR_SAMPSON)
             hipLaunchKernelGGL(ransac_score<PM_ERR_SAMPSON>, dim3(hb, chunks), dim3(256), 0, ctx->stream, dxy1, dxy2, n,
-                               d_n, chunk_len, models, nh, thr2, counts);
+                               d_n, chunk_len, sc.models, nh, thr2, sc.counts);
         else
             hipLaunchKernelGGL(ransac_score<PM_ERR_SYM_EPIPOLAR>, dim3(hb, chunks), dim3(256), 0, ctx->stream, dxy1,
-                               dxy2, n, d_n, chunk_len, models, nh, thr2, counts);
-        PM_HIP_CHECK(hipGetLastError());
-    }
-    {
-        pm::ScopedKernelTime t(ctx, "ransac_select");
-        hipLaunchKernelGGL(ransac_select, dim3(hb), dim3(256), 0, ctx->stream, models, counts, nh, p->hyp_begin, d_key);
+                               dxy2, n, d_n, chunk_len, sc.models, nh, thr2, sc.counts);
         PM_HIP_CHECK(hipGetLastError());
     }
     return PM_OK;
 }
 
-size_t shard_scratch_bytes(const pm_ransac_params* p)
+int select_shard(pm_ctx* ctx, const pm_ransac_params* p, unsigned long long* d_key, const ShardScratch& sc)
 {
-    const size_t nh = static_cast<size_t>(p->hyp_end - p->hyp_begin);
-    return pm::align_up(sizeof(float) * MODEL_STRIDE * nh, 256) + pm::align_up(sizeof(int) * nh, 256) + 256;
-}
-
-int finalize(pm_ctx* ctx, const float* dxy1, const float* dxy2, int n, const int* d_n, const pm_ransac_params* p,
-             const unsigned long long* d_key, FinalOut* d_fo, uint8_t* d_mask)
-{
-    pm::ScopedKernelTime t(ctx, "ransac_final");
-    hipLaunchKernelGGL(ransac_final_solve, dim3(1), dim3(64), 0, ctx->stream, dxy1, dxy2, n, d_n, p->seed, d_key,
-                       d_fo);
-    const float thr2 = p->thresh_px * p->thresh_px;
-    if (p->error_kind == PM_ERR_SAMPSON)
-        hipLaunchKernelGGL(ransac_final_mask<PM_ERR_SAMPSON>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, dxy1,
-                           dxy2, n, d_n, thr2, d_fo, d_mask);
-    else
-        hipLaunchKernelGGL(ransac_final_mask<PM_ERR_SYM_EPIPOLAR>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream,
-                           dxy1, dxy2, n, d_n, thr2, d_fo, d_mask);
+    const int nh = static_cast<int>(p->hyp_end - p->hyp_begin);
+    if (nh == 0) return PM_OK;
+    pm::ScopedKernelTime t(ctx, "ransac_select");
+    hipLaunchKernelGGL(ransac_select, dim3((nh + 255) / 256), dim3(256), 0, ctx->stream, sc.models, sc.counts, nh,
+                       p->hyp_begin, d_key);
     PM_HIP_CHECK(hipGetLastError());
     return PM_OK;
 }
 
-// Shared host-pointer driver: score (when hyp < 0) or take the given hypothesis, then finalise.
+int launch_mask(pm_ctx* ctx, const float* dxy1, const float* dxy2, int n, const int* d_n, const pm_ransac_params* p,
+                FinalOut* d_fo, uint8_t* d_mask, int* d_ninl)
+{
+    const float thr2 = p->thresh_px * p->thresh_px;
+    if (p->error_kind == PM_ERR_SAMPSON)
+        hipLaunchKernelGGL(ransac_final_mask<PM_ERR_SAMPSON>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, dxy1,
+                           dxy2, n, d_n, thr2, d_fo, d_mask, d_ninl);
+    else
+        hipLaunchKernelGGL(ransac_final_mask<PM_ERR_SYM_EPIPOLAR>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream,
+                           dxy1, dxy2, n, d_n, thr2, d_fo, d_mask, d_ninl);
+    PM_HIP_CHECK(hipGetLastError());
+    return PM_OK;
+}
+
+// finalise from a key that may name ANY id (re-solves it)
+int finalize_from_key(pm_ctx* ctx, const float* dxy1, const float* dxy2, int n, const int* d_n,
+                      const pm_ransac_params* p, const unsigned long long* d_key, FinalOut* d_fo, double* d_F,
+                      uint8_t* d_mask, int* d_ninl)
+{
+    pm::ScopedKernelTime t(ctx, "ransac_final");
+    hipLaunchKernelGGL(ransac_final_solve, dim3(1), dim3(64), 0, ctx->stream, dxy1, dxy2, n, d_n, p->seed, d_key,
+                       d_fo, d_F, d_ninl);
+    return launch_mask(ctx, dxy1, dxy2, n, d_n, p, d_fo, d_mask, d_ninl);
+}
+
+// finalise the winner of the shard just scored (stored fp64 model, no second solve)
+int finalize_local(pm_ctx* ctx, const float* dxy1, const float* dxy2, int n, const int* d_n,
+                   const pm_ransac_params* p, unsigned long long* d_key, const ShardScratch& sc, double* d_F,
+                   uint8_t* d_mask, int* d_ninl)
+{
+    const int nh = static_cast<int>(p->hyp_end - p->hyp_begin);
+    pm::ScopedKernelTime t(ctx, "ransac_final");
+    hipLaunchKernelGGL(ransac_pick, dim3(1), dim3(1024), 0, ctx->stream, sc.models, sc.models64, sc.counts, nh,
+                       p->hyp_begin, d_key, sc.fo, d_F, d_ninl);
+    return launch_mask(ctx, dxy1, dxy2, n, d_n, p, sc.fo, d_mask, d_ninl);
+}
+
+// Shared host-pointer driver: run the shard (hyp < 0) or take the given hypothesis, then finalise.
 int host_run(pm_ctx* ctx, const float* xy1, const float* xy2, int n, const pm_ransac_params* p, int64_t hyp,
              double F[9], uint8_t* mask, int* n_inliers, uint64_t* best_key)
 {
@@ -483,7 +600,7 @@ int host_run(pm_ctx* ctx, const float* xy1, const float* xy2, int n, const pm_ra
 
     const size_t xyb = sizeof(float) * 2 * static_cast<size_t>(n);
     const size_t need = 2 * pm::align_up(xyb, 256) + pm::align_up(static_cast<size_t>(n), 256) + 512 +
-                        shard_scratch_bytes(p) + 1024;
+                        shard_scratch_bytes(p) + 2048;
     rc = pm::arena_reserve(ctx, need);
     if (rc != PM_OK) return rc;
     pm::arena_reset(ctx);
@@ -491,31 +608,36 @@ int host_run(pm_ctx* ctx, const float* xy1, const float* xy2, int n, const pm_ra
     float* dxy2 = static_cast<float*>(pm::arena_take(ctx, xyb));
     uint8_t* dmask = static_cast<uint8_t*>(pm::arena_take(ctx, static_cast<size_t>(n)));
     unsigned long long* dkey = static_cast<unsigned long long*>(pm::arena_take(ctx, 8));
-    FinalOut* dfo = static_cast<FinalOut*>(pm::arena_take(ctx, sizeof(FinalOut)));
-    char* scratch = static_cast<char*>(pm::arena_take(ctx, shard_scratch_bytes(p)));
-    PM_REQUIRE(dxy1 && dxy2 && dmask && dkey && dfo && scratch, PM_E_NOMEM, "scratch arena too small");
+    PM_REQUIRE(dxy1 && dxy2 && dmask && dkey, PM_E_NOMEM, "scratch arena too small");
+    ShardScratch sc;
+    rc = take_scratch(ctx, p, sc);
+    if (rc != PM_OK) return rc;
     rc = pm::pinned_reserve(ctx, sizeof(FinalOut) + 8 + static_cast<size_t>(n));
     if (rc != PM_OK) return rc;
 
     PM_HIP_CHECK(hipMemcpyAsync(dxy1, xy1, xyb, hipMemcpyHostToDevice, ctx->stream));
     PM_HIP_CHECK(hipMemcpyAsync(dxy2, xy2, xyb, hipMemcpyHostToDevice, ctx->stream));
     if (hyp < 0) {
-        rc = score_shard(ctx, dxy1, dxy2, n, nullptr, p, dkey, scratch);
+        rc = score_shard(ctx, dxy1, dxy2, n, nullptr, p, dkey, sc);
         if (rc != PM_OK) return rc;
+        if (p->hyp_end > p->hyp_begin)
+            rc = finalize_local(ctx, dxy1, dxy2, n, nullptr, p, dkey, sc, nullptr, dmask, nullptr);
+        else
+            rc = finalize_from_key(ctx, dxy1, dxy2, n, nullptr, p, dkey, sc.fo, nullptr, dmask, nullptr);
     } else {
         const unsigned long long k = pm_ransac_key(0u, static_cast<uint32_t>(hyp)) | (1ull << 32);  // non-zero
         unsigned long long* hk = static_cast<unsigned long long*>(ctx->pinned);
         *hk = k;
         PM_HIP_CHECK(hipMemcpyAsync(dkey, hk, 8, hipMemcpyHostToDevice, ctx->stream));
+        rc = finalize_from_key(ctx, dxy1, dxy2, n, nullptr, p, dkey, sc.fo, nullptr, dmask, nullptr);
     }
-    rc = finalize(ctx, dxy1, dxy2, n, nullptr, p, dkey, dfo, dmask);
     if (rc != PM_OK) return rc;
     char* hp = static_cast<char*>(ctx->pinned);
     FinalOut* hfo = reinterpret_cast<FinalOut*>(hp + 8);
     uint8_t* hmask = reinterpret_cast<uint8_t*>(hp + 8 + sizeof(FinalOut));
     unsigned long long* hkey = reinterpret_cast<unsigned long long*>(hp);
     PM_HIP_CHECK(hipMemcpyAsync(hkey, dkey, 8, hipMemcpyDeviceToHost, ctx->stream));
-    PM_HIP_CHECK(hipMemcpyAsync(hfo, dfo, sizeof(FinalOut), hipMemcpyDeviceToHost, ctx->stream));
+    PM_HIP_CHECK(hipMemcpyAsync(hfo, sc.fo, sizeof(FinalOut), hipMemcpyDeviceToHost, ctx->stream));
     PM_HIP_CHECK(hipMemcpyAsync(hmask, dmask, static_cast<size_t>(n), hipMemcpyDeviceToHost, ctx->stream));
     PM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (best_key && hyp < 0) *best_key = *hkey;
@@ -527,6 +649,20 @@ int host_run(pm_ctx* ctx, const float* xy1, const float* xy2, int n, const pm_ra
     if (mask) memcpy(mask, hmask, static_cast<size_t>(n));
     if (n_inliers) *n_inliers = hfo->n_inliers;
     return PM_OK;
+}
+
+int dev_prologue(pm_ctx* ctx, const pm_ransac_params* p, int n_max, const float* d_xy1, const float* d_xy2,
+                 ShardScratch& sc)
+{
+    PM_REQUIRE(ctx != nullptr, PM_E_INVALID, "ctx is null");
+    int rc = check_params(p);
+    if (rc != PM_OK) return rc;
+    PM_REQUIRE(n_max >= 1 && d_xy1 && d_xy2, PM_E_INVALID, "bad point arrays");
+    PM_HIP_CHECK(hipSetDevice(ctx->device));
+    rc = pm::arena_reserve(ctx, shard_scratch_bytes(p) + 2048);
+    if (rc != PM_OK) return rc;
+    pm::arena_reset(ctx);
+    return take_scratch(ctx, p, sc);
 }
 
 }  // namespace
@@ -551,34 +687,43 @@ extern "C" int pm_ransac_model_from_hyp(pm_ctx* ctx, const float* xy1, const flo
 extern "C" int pm_ransac_score_dev(pm_ctx* ctx, const float* d_xy1, const float* d_xy2, int n,
                                    const pm_ransac_params* p, uint64_t* d_best_key)
 {
-    PM_REQUIRE(ctx != nullptr && d_best_key != nullptr, PM_E_INVALID, "null argument");
-    int rc = check_params(p);
+    PM_REQUIRE(d_best_key != nullptr, PM_E_INVALID, "null argument");
+    if (n >= 0 && n < 8) { pm::set_error("need at least 8 correspondences, got %d", n); return PM_E_TOO_FEW; }
+    ShardScratch sc;
+    int rc = dev_prologue(ctx, p, n, d_xy1, d_xy2, sc);
     if (rc != PM_OK) return rc;
-    PM_REQUIRE(n >= 0 && (n == 0 || (d_xy1 && d_xy2)), PM_E_INVALID, "bad point arrays");
-    if (n < 8) { pm::set_error("need at least 8 correspondences, got %d", n); return PM_E_TOO_FEW; }
-    PM_HIP_CHECK(hipSetDevice(ctx->device));
-    rc = pm::arena_reserve(ctx, shard_scratch_bytes(p) + 1024);
+    unsigned long long* key = reinterpret_cast<unsigned long long*>(d_best_key);
+    rc = score_shard(ctx, d_xy1, d_xy2, n, nullptr, p, key, sc);
     if (rc != PM_OK) return rc;
-    pm::arena_reset(ctx);
-    char* scratch = static_cast<char*>(pm::arena_take(ctx, shard_scratch_bytes(p)));
-    PM_REQUIRE(scratch != nullptr, PM_E_NOMEM, "scratch arena too small");
-    return score_shard(ctx, d_xy1, d_xy2, n, nullptr, p, reinterpret_cast<unsigned long long*>(d_best_key), scratch);
+    return select_shard(ctx, p, key, sc);
 }
 
 extern "C" int pm_ransac_score_devn(pm_ctx* ctx, const float* d_xy1, const float* d_xy2, int n_max,
                                     const int32_t* d_n, const pm_ransac_params* p, uint64_t* d_best_key)
 {
-    PM_REQUIRE(ctx != nullptr && d_best_key != nullptr && d_n != nullptr, PM_E_INVALID, "null argument");
-    int rc = check_params(p);
+    PM_REQUIRE(d_best_key != nullptr && d_n != nullptr, PM_E_INVALID, "null argument");
+    ShardScratch sc;
+    int rc = dev_prologue(ctx, p, n_max, d_xy1, d_xy2, sc);
     if (rc != PM_OK) return rc;
-    PM_REQUIRE(n_max >= 1 && d_xy1 && d_xy2, PM_E_INVALID, "bad point arrays");
-    PM_HIP_CHECK(hipSetDevice(ctx->device));
-    rc = pm::arena_reserve(ctx, shard_scratch_bytes(p) + 1024);
+    unsigned long long* key = reinterpret_cast<unsigned long long*>(d_best_key);
+    rc = score_shard(ctx, d_xy1, d_xy2, n_max, d_n, p, key, sc);
     if (rc != PM_OK) return rc;
-    pm::arena_reset(ctx);
-    char* scratch = static_cast<char*>(pm::arena_take(ctx, shard_scratch_bytes(p)));
-    PM_REQUIRE(scratch != nullptr, PM_E_NOMEM, "scratch arena too small");
-    return score_shard(ctx, d_xy1, d_xy2, n_max, d_n, p, reinterpret_cast<unsigned long long*>(d_best_key), scratch);
+    return select_shard(ctx, p, key, sc);
+}
+
+extern "C" int pm_ransac_run_dev(pm_ctx* ctx, const float* d_xy1, const float* d_xy2, int n_max, const int32_t* d_n,
+                                 const pm_ransac_params* p, uint64_t* d_best_key, double* d_F, uint8_t* d_mask,
+                                 int32_t* d_n_inliers)
+{
+    PM_REQUIRE(d_best_key && d_F && d_mask && d_n_inliers, PM_E_INVALID, "null argument");
+    ShardScratch sc;
+    int rc = dev_prologue(ctx, p, n_max, d_xy1, d_xy2, sc);
+    if (rc != PM_OK) return rc;
+    PM_REQUIRE(p->hyp_end > p->hyp_begin, PM_E_INVALID, "empty hypothesis range");
+    unsigned long long* key = reinterpret_cast<unsigned long long*>(d_best_key);
+    rc = score_shard(ctx, d_xy1, d_xy2, n_max, d_n, p, key, sc);
+    if (rc != PM_OK) return rc;
+    return finalize_local(ctx, d_xy1, d_xy2, n_max, d_n, p, key, sc, d_F, d_mask, d_n_inliers);
 }
 
 extern "C" int pm_ransac_model_from_key_dev(pm_ctx* ctx, const float* d_xy1, const float* d_xy2, int n_max,
@@ -595,9 +740,6 @@ extern "C" int pm_ransac_model_from_key_dev(pm_ctx* ctx, const float* d_xy1, con
     pm::arena_reset(ctx);
     FinalOut* dfo = static_cast<FinalOut*>(pm::arena_take(ctx, sizeof(FinalOut)));
     PM_REQUIRE(dfo != nullptr, PM_E_NOMEM, "scratch arena too small");
-    rc = finalize(ctx, d_xy1, d_xy2, n_max, d_n, p, reinterpret_cast<const unsigned long long*>(d_key), dfo, d_mask);
-    if (rc != PM_OK) return rc;
-    PM_HIP_CHECK(hipMemcpyAsync(d_F, dfo->F, sizeof(double) * 9, hipMemcpyDeviceToDevice, ctx->stream));
-    PM_HIP_CHECK(hipMemcpyAsync(d_n_inliers, &dfo->n_inliers, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
-    return PM_OK;
+    return finalize_from_key(ctx, d_xy1, d_xy2, n_max, d_n, p, reinterpret_cast<const unsigned long long*>(d_key), dfo,
+                             d_F, d_mask, d_n_inliers);
 }

@@ -41,6 +41,17 @@ def test_device_pipeline_matches_host_stages(ctx, oracle):
                                       d_key.data_ptr(), d_F.data_ptr(), d_mask.data_ptr(), d_ninl.data_ptr())
         ctx.synchronize()
         ctx.set_stream(0)
+    # the fused single-shard run must publish the same key / F / mask / count
+    d_key2 = torch.zeros(1, dtype=torch.int64, device=dev)
+    d_F2 = torch.zeros(9, dtype=torch.float64, device=dev)
+    d_mask2 = torch.full((nq,), 7, dtype=torch.uint8, device=dev)
+    d_ninl2 = torch.full((1,), 99, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.ransac_run_dev(d_xy1.data_ptr(), d_xy2.data_ptr(), nq, d_n.data_ptr(), 0, 800, 1.0, 11, d_key2.data_ptr(),
+                       d_F2.data_ptr(), d_mask2.data_ptr(), d_ninl2.data_ptr())
+    ctx.synchronize()
+    assert int(d_key2.item()) == int(d_key.item()) and int(d_ninl2.item()) == int(d_ninl.item())
+    assert torch.equal(d_F2, d_F) and torch.equal(d_mask2, d_mask)
     knn = d_knn.cpu().numpy().view(pm.MATCH_DTYPE).reshape(nq, K)
     want_knn = oracle.bf_knn_l2(w["q"], w["t"], K)
     assert_matches_equal(knn, want_knn, "dev knn")
@@ -81,6 +92,8 @@ def test_concat_points(ctx):
 
 def test_knn_stats_report_refinement(ctx):
     q, t, _ = synth.surf_like(1024, 1024, 128, seed=2)
+    ctx.knn_diag_enable(True)
     ctx.bf_knn_l2(q, t, 2)
     st = ctx.knn_stats()
+    ctx.knn_diag_enable(False)
     assert st["nonfinite"] == 0 and st["rescans"] < 32      # the MFMA route, not the re-scan, did the work
