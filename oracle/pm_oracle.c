@@ -317,7 +317,7 @@ int pmo_solve8(const double* p1, const double* p2, double F[9])
             double al = G[0][p] * G[0][p]; al = fma(G[1][p], G[1][p], al); al = fma(G[2][p], G[2][p], al);
             double be = G[0][q] * G[0][q]; be = fma(G[1][q], G[1][q], be); be = fma(G[2][q], G[2][q], be);
             double ga = G[0][p] * G[0][q]; ga = fma(G[1][p], G[1][q], ga); ga = fma(G[2][p], G[2][q], ga);
-            if (ga == 0.0 || ga != ga) continue;
+            if (!(ga * ga > 4.930380657631324e-32 * (al * be))) continue;   /* converged (or NaN) pair */
             double zeta = (be - al) / (2.0 * ga);
             double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(fma(zeta, zeta, 1.0)));
             double c = 1.0 / sqrt(fma(t, t, 1.0));

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpm_hip.so")
+LIB_PATH = os.environ.get("PM_LIB_PATH") or os.path.join(_HERE, "libpm_hip.so")   # override: experiments only
 
 MATCH_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"),
                         ("distance", "<f4")])

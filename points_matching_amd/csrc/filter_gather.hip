@@ -8,77 +8,100 @@
 
 namespace {
 
-// One workgroup of 1024 threads; a thread owns FG_ITEMS consecutive rows (a contiguous 256-byte
-// read at k = 2), so 8192 rows need a single scan: ballot-free local prefix + one wave scan + a
-// 16-entry scan across waves.  Longer inputs loop with a running base.
-constexpr int FG_ITEMS = 8;
+// Stable compaction in ONE launch, decoupled look-back style.  Block b owns rows
+// [b*FG_ROWS, (b+1)*FG_ROWS): it evaluates its own rows, publishes its survivor count as an
+// epoch-tagged word (agent-scope relaxed store), and obtains its output offset from the counts of
+// blocks 0..b-1, which it polls with agent-scope relaxed loads (one word per polling lane).
+// Blocks only ever wait for LOWER block ids and the grid (nq/256 blocks) is far below what the
+// chip keeps resident, so the wait terminates; it is bounded anyway: a poller that gives up
+// re-derives the missing count from the k-NN records itself (always correct, just slower).
+// The tag (epoch << 10 | count) makes clearing the words between calls unnecessary.
+constexpr int FG_ROWS = 256;
+constexpr int FG_MAX_BLOCKS = 4096;          // 1M query rows; more -> the caller is told so
+constexpr unsigned FG_SPIN_LIMIT = 200000u;
 
-__global__ __launch_bounds__(1024) void filter_ratio_gather(const pm_match* __restrict__ knn, int nq, int k,
-                                                            float ratio, const float* __restrict__ kp1,
-                                                            const float* __restrict__ kp2,
-                                                            pm_match* __restrict__ good, float* __restrict__ xy1,
-                                                            float* __restrict__ xy2, int* __restrict__ n_out)
+__device__ __forceinline__ bool fg_keep(const pm_match* __restrict__ knn, int i, int k, float ratio, pm_match& best)
 {
-    __shared__ int wave_tot[16];
-    __shared__ int base_sh;
+    const uint4 a = *reinterpret_cast<const uint4*>(knn + static_cast<size_t>(i) * k);
+    const uint4 b = *reinterpret_cast<const uint4*>(knn + static_cast<size_t>(i) * k + 1);
+    best.queryIdx = static_cast<int>(a.x); best.trainIdx = static_cast<int>(a.y);
+    best.imgIdx = static_cast<int>(a.z);   best.distance = __uint_as_float(a.w);
+    const float rhs = ratio * __uint_as_float(b.w);
+    return static_cast<int>(a.y) >= 0 && static_cast<int>(b.y) >= 0 && best.distance < rhs;
+}
+
+__global__ __launch_bounds__(FG_ROWS) void filter_ratio_gather(const pm_match* __restrict__ knn, int nq, int k,
+                                                               float ratio, const float* __restrict__ kp1,
+                                                               const float* __restrict__ kp2,
+                                                               pm_match* __restrict__ good, float* __restrict__ xy1,
+                                                               float* __restrict__ xy2, int* __restrict__ n_out,
+                                                               unsigned* __restrict__ blk_counts, unsigned epoch)
+{
+    __shared__ int wave_cnt[FG_ROWS / 64];
+    __shared__ int wave_pre[FG_ROWS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) base_sh = 0;
-    __syncthreads();
-    for (int start = 0; start < nq; start += 1024 * FG_ITEMS) {
-        const int i0 = start + tid * FG_ITEMS;
-        pm_match best[FG_ITEMS];
-        unsigned keep = 0u;
-        // unconditional loads from clamped rows (a load under a per-element branch makes hipcc wait
-        // for each one in turn); the row guard is applied to the flag instead
-        pm_match second[FG_ITEMS];
-#pragma unroll
-        for (int e = 0; e < FG_ITEMS; ++e) {
-            const int i = i0 + e < nq ? i0 + e : nq - 1;
-            best[e] = knn[static_cast<size_t>(i) * k];
-            second[e] = knn[static_cast<size_t>(i) * k + 1];
-        }
-        float2 pa[FG_ITEMS], pb[FG_ITEMS];
-#pragma unroll
-        for (int e = 0; e < FG_ITEMS; ++e) {
-            const float rhs = ratio * second[e].distance;
-            const bool ok = i0 + e < nq && best[e].trainIdx >= 0 && second[e].trainIdx >= 0 && best[e].distance < rhs;
-            if (ok) keep |= 1u << e;
-            if (kp1) {
-                const int ti = best[e].trainIdx >= 0 ? best[e].trainIdx : 0;
-                pa[e] = *reinterpret_cast<const float2*>(kp1 + 2 * static_cast<size_t>(best[e].queryIdx));
-                pb[e] = *reinterpret_cast<const float2*>(kp2 + 2 * static_cast<size_t>(ti));
-            }
-        }
-        const int mine = __popc(keep);
-        int incl = mine;                                    // inclusive scan over the wave
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += v;
-        }
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        int off = base_sh + incl - mine;
-        for (int w = 0; w < wave; ++w) off += wave_tot[w];
-#pragma unroll
-        for (int e = 0; e < FG_ITEMS; ++e)
-            if (keep & (1u << e)) {
-                good[off] = best[e];
-                if (kp1) {
-                    *reinterpret_cast<float2*>(xy1 + 2 * static_cast<size_t>(off)) = pa[e];
-                    *reinterpret_cast<float2*>(xy2 + 2 * static_cast<size_t>(off)) = pb[e];
-                }
-                ++off;
-            }
-        __syncthreads();
-        if (tid == 0) {
-            int tot = 0;
-            for (int w = 0; w < 16; ++w) tot += wave_tot[w];
-            base_sh += tot;
-        }
-        __syncthreads();
+    const int b = blockIdx.x;
+    const int i = b * FG_ROWS + tid;
+
+    // own row (clamped load, guard on the flag) and the keypoints it would carry
+    pm_match best;
+    const bool keep = fg_keep(knn, i < nq ? i : nq - 1, k, ratio, best) && i < nq;
+    float2 pa = {0.f, 0.f}, pb = {0.f, 0.f};
+    if (kp1) {
+        pa = *reinterpret_cast<const float2*>(kp1 + 2 * static_cast<size_t>(best.queryIdx));
+        pb = *reinterpret_cast<const float2*>(kp2 + 2 * static_cast<size_t>(best.trainIdx >= 0 ? best.trainIdx : 0));
     }
-    if (tid == 0) *n_out = base_sh;
+    const unsigned long long bal = __ballot(keep);
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int mine = 0;
+#pragma unroll
+    for (int w = 0; w < FG_ROWS / 64; ++w) mine += wave_cnt[w];
+    if (tid == 0)
+        __hip_atomic_store(&blk_counts[b], (epoch << 10) | static_cast<unsigned>(mine), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+
+    // counts of the blocks before this one: lane t polls block t, t+256, ...
+    int before = 0;
+    for (int pb_ = tid; pb_ < b; pb_ += FG_ROWS) {
+        unsigned v = 0u, spins = 0u;
+        for (;;) {
+            v = __hip_atomic_load(&blk_counts[pb_], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((v >> 10) == epoch || ++spins > FG_SPIN_LIMIT) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if ((v >> 10) == epoch) {
+            before += static_cast<int>(v & 1023u);
+        } else {                                   // gave up: count that block's survivors directly
+            pm_match tmp;
+            for (int r = 0; r < FG_ROWS; ++r) {
+                const int row = pb_ * FG_ROWS + r;
+                before += fg_keep(knn, row, k, ratio, tmp) ? 1 : 0;       // row < b*FG_ROWS <= nq
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+    if (lane == 0) wave_pre[wave] = before;
+    __syncthreads();
+    int off = __popcll(bal & ((1ull << lane) - 1ull));
+#pragma unroll
+    for (int w = 0; w < FG_ROWS / 64; ++w) {
+        off += wave_pre[w];
+        if (w < wave) off += wave_cnt[w];
+    }
+    if (keep) {
+        good[off] = best;
+        if (kp1) {
+            *reinterpret_cast<float2*>(xy1 + 2 * static_cast<size_t>(off)) = pa;
+            *reinterpret_cast<float2*>(xy2 + 2 * static_cast<size_t>(off)) = pb;
+        }
+    }
+    if (b == static_cast<int>(gridDim.x) - 1 && tid == 0) {
+        int tot = mine;
+        for (int w = 0; w < FG_ROWS / 64; ++w) tot += wave_pre[w];
+        *n_out = tot;
+    }
 }
 
 // Concatenates `parts` padded point blocks (each `stride` points, counts[p] valid) into one
@@ -121,8 +144,23 @@ extern "C" int pm_filter_ratio_gather_dev(pm_ctx* ctx, const pm_match* d_knn, in
     PM_REQUIRE(d_kp1_xy == nullptr || (d_xy1 && d_xy2), PM_E_INVALID, "null point outputs");
     PM_HIP_CHECK(hipSetDevice(ctx->device));
     pm::ScopedKernelTime t(ctx, "filter_gather");
-    hipLaunchKernelGGL(filter_ratio_gather, dim3(1), dim3(1024), 0, ctx->stream, d_knn, nq, k, ratio, d_kp1_xy,
-                       d_kp2_xy, d_good, d_xy1, d_xy2, d_n_good);
+    if (nq == 0) {
+        PM_HIP_CHECK(hipMemsetAsync(d_n_good, 0, sizeof(int32_t), ctx->stream));
+        return PM_OK;
+    }
+    const int nblk = (nq + FG_ROWS - 1) / FG_ROWS;
+    PM_REQUIRE(nblk <= FG_MAX_BLOCKS, PM_E_UNSUPPORTED, "more than 1M query rows per compaction call");
+    if (!ctx->fg_counts) {
+        PM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ctx->fg_counts), sizeof(unsigned) * FG_MAX_BLOCKS));
+        PM_HIP_CHECK(hipMemsetAsync(ctx->fg_counts, 0, sizeof(unsigned) * FG_MAX_BLOCKS, ctx->stream));
+        ctx->fg_epoch = 0;
+    }
+    if (++ctx->fg_epoch >= (1u << 22)) {          // 22-bit tag: restart
+        PM_HIP_CHECK(hipMemsetAsync(ctx->fg_counts, 0, sizeof(unsigned) * FG_MAX_BLOCKS, ctx->stream));
+        ctx->fg_epoch = 1;
+    }
+    hipLaunchKernelGGL(filter_ratio_gather, dim3(nblk), dim3(FG_ROWS), 0, ctx->stream, d_knn, nq, k, ratio, d_kp1_xy,
+                       d_kp2_xy, d_good, d_xy1, d_xy2, d_n_good, ctx->fg_counts, ctx->fg_epoch);
     PM_HIP_CHECK(hipGetLastError());
     return PM_OK;
 }

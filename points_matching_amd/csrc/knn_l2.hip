@@ -20,6 +20,8 @@
 //                  VALU out of LDS tiles.  Also the `PM_KNN_FORCE_EXACT` path.
 //
 // Both routes are bit-identical by construction (tests/test_knn_l2_gpu.py asserts it).
+#include <cstdlib>
+
 #include "pm_common.hpp"
 
 namespace {
@@ -133,7 +135,10 @@ __global__ __launch_bounds__(256) void knn_l2_prep(const float* __restrict__ Q, 
         const int rl = row < n ? row : n - 1;
         const float* p = x + static_cast<size_t>(rl) * dim;
         float s = 0.f;
-        for (int c = sub; c < dim; c += 16) s = fmaf(p[c], p[c], s);
+        for (int c = 4 * sub; c < dim; c += 64) {            // dim % 4 == 0 on this route
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p + c);
+            s = fmaf(v[0], v[0], s); s = fmaf(v[1], v[1], s); s = fmaf(v[2], v[2], s); s = fmaf(v[3], v[3], s);
+        }
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
         if (sub == 0 && row < n) {
@@ -161,9 +166,8 @@ __global__ __launch_bounds__(256) void knn_l2_prep(const float* __restrict__ Q, 
 // ---------------------------------------------------------------------------------------------
 // coarse pass on the matrix cores
 //
-// Per (query, train row) the accumulator is seeded with -||t||^2/2 and the MFMA chain adds q.t, so
-// it ends as w = q.t - ||t||^2/2 = -(d2a - ||q||^2)/2: the LARGEST w are the nearest rows, and no
-// VALU work is needed to form the ranking value.  The row's position in this lane's stream
+// Per (query, train row) the MFMA chain accumulates w = q.t - ||t||^2/2 = -(d2a - ||q||^2)/2 (the
+// seed -||t||^2/2 is one more k-step of the chain): the LARGEST w are the nearest rows.  The row's position in this lane's stream
 // (lid = tile_in_split*32 + block*16 + reg) is written into the low `bits` mantissa bits of w, so
 // a candidate is ONE float and keeping the 4 largest is branch-free:
 //     n0 = max(x,w0); n1 = med3(x,w0,w1); n2 = med3(x,w1,w2); n3 = med3(x,w2,w3)
@@ -175,29 +179,50 @@ constexpr float KNN_BIG = 3.0e38f;       // finite sentinel: stays finite under 
 
 __device__ __forceinline__ float embed_lid(float w, unsigned keep_mask, unsigned lid)
 {
-    return __uint_as_float((__float_as_uint(w) & keep_mask) | lid);
+    // (keep & w) | (~keep & lid) as ONE instruction: v_bfi_b32 D = (S0 & S1) | (~S0 & S2)
+    float r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(keep_mask), "v"(w), "v"(lid));
+    return r;
+}
+
+// The builtin forms make hipcc put a canonicalising v_max_f32 x,x in front of every operand
+// (IEEE mode: the result of fmax/fmed3 must be quiet), three extra VALU ops per candidate.
+// The operands here are finite by construction (non-finite inputs divert to the re-scan), so the
+// bare instructions are used; plain asm (not volatile) stays freely schedulable.
+__device__ __forceinline__ float raw_max(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float raw_med3(float a, float b, float c)
+{
+    float r;
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
 
 __device__ __forceinline__ void top4_insert(f32x4& c, float x)
 {
-    const float n0 = __builtin_amdgcn_fmed3f(x, c[0], KNN_INF);      // = max(x, c0), no canonicalising v_max
-    const float n1 = __builtin_amdgcn_fmed3f(x, c[0], c[1]);
-    const float n2 = __builtin_amdgcn_fmed3f(x, c[1], c[2]);
-    const float n3 = __builtin_amdgcn_fmed3f(x, c[2], c[3]);
+    const float n0 = raw_max(x, c[0]);
+    const float n1 = raw_med3(x, c[0], c[1]);
+    const float n2 = raw_med3(x, c[1], c[2]);
+    const float n3 = raw_med3(x, c[2], c[3]);
     c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
 }
 
-// NCH = padded dim / 8; FULL = (dim == 8*NCH), which drops the column guards.
-// grid = (ceil(nq/QB), splits).  Dynamic LDS: 2 tiles of TILE_T x (8*NCH + 4) floats (row stride
-// padded by one 16-B slot: conflict-free ds_read_b128 for the 16 rows of a lane group) + 2 x TILE_T
-// seeds (-||t||^2/2, or -KNN_BIG/2 past the last row).
-template <int NCH, bool FULL>
+// NCH = padded dim / 8; FULL = (dim == 8*NCH), which drops the column guards; TT = train rows
+// per LDS tile (64: two workgroups per CU, 128: one workgroup per CU with twice the MFMA work
+// between barriers).  grid = (ceil(nq/QB), splits).  Dynamic LDS: 2 tiles of TT x (8*NCH + 4)
+// floats (row stride padded by one 16-B slot: conflict-free ds_read_b128 for the 16 rows of a lane
+// group) + 2 x TT seeds (-||t||^2/2, or -KNN_BIG/2 past the last row).
+template <int NCH, bool FULL, int TT>
 struct KnnTile {
     static constexpr int DP = NCH * 8;
     static constexpr int LDT = DP + 4;
     static constexpr int F4_PER_ROW = DP / 4;
-    static constexpr int NSTG = TILE_T * F4_PER_ROW / 256;
-    static_assert(TILE_T * F4_PER_ROW % 256 == 0, "tile must split evenly over the workgroup");
+    static constexpr int NSTG = TT * F4_PER_ROW / 256;
+    static_assert(TT * F4_PER_ROW % 256 == 0, "tile must split evenly over the workgroup");
 
     f32x4 stg[NSTG];
     float stg_n;
@@ -210,7 +235,7 @@ struct KnnTile {
         for (int i = 0; i < NSTG; ++i) {
             const int f = tid + 256 * i;
             const int row = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
-            int g = tile * TILE_T + row;
+            int g = tile * TT + row;
             g = g < nt ? g : nt - 1;
             int col = 4 * c4;
             if (!FULL) col = col < dim ? col : dim - 4;
@@ -218,87 +243,125 @@ struct KnnTile {
             if (!FULL && 4 * c4 >= dim) v = f32x4{0.f, 0.f, 0.f, 0.f};
             stg[i] = v;
         }
-        const int gn = tile * TILE_T + (tid & (TILE_T - 1));
+        const int gn = tile * TT + (tid & (TT - 1));
         const float nrm = tnorm[gn < nt ? gn : nt - 1];
         stg_n = gn < nt ? -0.5f * nrm : -0.5f * KNN_BIG;
     }
     // registers -> LDS buffer
-    __device__ __forceinline__ void store(float* __restrict__ Ts, float* __restrict__ Tn, int buf, int tid) const
+    // the row seed -||t||^2/2 travels in the row's 16-byte pad slot: (seed, 0, 0, 0)
+    __device__ __forceinline__ void store(float* __restrict__ Ts, int buf, int tid) const
     {
 #pragma unroll
         for (int i = 0; i < NSTG; ++i) {
             const int f = tid + 256 * i;
             const int row = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
-            *reinterpret_cast<f32x4*>(Ts + (buf * TILE_T + row) * LDT + 4 * c4) = stg[i];
+            *reinterpret_cast<f32x4*>(Ts + (buf * TT + row) * LDT + 4 * c4) = stg[i];
         }
-        if (tid < TILE_T) Tn[buf * TILE_T + tid] = stg_n;
+        if (tid < TT) *reinterpret_cast<f32x4*>(Ts + (buf * TT + tid) * LDT + DP) = f32x4{stg_n, 0.f, 0.f, 0.f};
     }
 };
 
-// One tile: seed the accumulators, run the MFMA chain, and (EPI) select the previous tile's
-// accumulators p0/p1 in between.  C[i][j] of lane (j = lane&31), register reg is train row
-// i = (reg&3) + 8*(reg>>2) + 4*(lane>>5) of the 32-row block.
-template <int NCH, bool EPI>
-__device__ __forceinline__ void knn_tile_compute(const float* __restrict__ Ts, const float* __restrict__ Tn,
-                                                 int buf, int r, int h, const f32x4 (&qf)[NCH], f32x16& a0,
-                                                 f32x16& a1, const f32x16& p0, const f32x16& p1, unsigned pbase,
-                                                 unsigned keep_mask, f32x4& cl)
+// One tile of the sweep.  Everything that is not an MFMA is issued INSIDE the chain, in the shadow
+// of a 64-cycle MFMA: the global loads of the next tile after chunk 0, the selection of the
+// previous tile's accumulators p[] spread over all chunks, and the LDS writes of the next tile
+// after the last-but-one chunk.  The row seed -||t||^2/2 enters through the matrix pipe as well:
+// one extra k-step per block multiplies the pad column (seed, 0) of the A tile by (1, 0), starting
+// from the inline constant C = 0, so no accumulator is initialised and the selection needs no
+// add.  The next tile is always staged (clamped addresses; past the end the data is unused),
+// which keeps the chain free of branches.
+// C[i][j] of lane (j = lane&31), register reg is train row i = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+template <int NCH, bool FULL, int NB, bool EPI>
+__device__ __forceinline__ void knn_tile_compute(float* __restrict__ Ts, int buf, int r, int h,
+                                                 const f32x4 (&qf)[NCH], f32x16 (&a)[NB], const f32x16 (&p)[NB],
+                                                 unsigned pbase, unsigned keep_mask, f32x4& cl,
+                                                 KnnTile<NCH, FULL, NB * 32>& st, const float* __restrict__ T,
+                                                 const float* __restrict__ tnorm, int next_tile, int nt, int dim,
+                                                 int tid)
 {
-    constexpr int LDT = NCH * 8 + 4;
-    const float* tn = Tn + buf * TILE_T + 4 * h;
+    constexpr int DP = NCH * 8;
+    constexpr int LDT = DP + 4;
+    constexpr int TT = NB * 32;
+    static_assert(NCH >= 4, "the in-chain schedule needs at least 4 chunks");
+    const float* tb = Ts + buf * TT * LDT + r * LDT + 4 * h;
+    const float one_or_zero = h == 0 ? 1.f : 0.f;          // B side of the seed step: k = h
+    float sda[NB];                                          // A side: pad[h] = (seed, 0)[h]
+    f32x4 xn[NB];                                           // A fragments, one chunk ahead of their MFMAs
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const f32x4 n0 = *reinterpret_cast<const f32x4*>(tn + 8 * g);
-        const f32x4 n1 = *reinterpret_cast<const f32x4*>(tn + 32 + 8 * g);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { a0[4 * g + e] = n0[e]; a1[4 * g + e] = n1[e]; }
+    for (int blk = 0; blk < NB; ++blk) {
+        sda[blk] = Ts[buf * TT * LDT + (32 * blk + r) * LDT + DP + h];
+        xn[blk] = *reinterpret_cast<const f32x4*>(tb + 32 * blk * LDT);
     }
-    const float* tb = Ts + buf * TILE_T * LDT + r * LDT + 4 * h;
+    {
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk)
+            a[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(sda[blk], one_or_zero, zero, 0, 0, 0);
+    }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const f32x4 x0 = *reinterpret_cast<const f32x4*>(tb + 8 * c);
-        const f32x4 x1 = *reinterpret_cast<const f32x4*>(tb + 32 * LDT + 8 * c);
+        f32x4 x[NB];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[t], qf[c][t], a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[t], qf[c][t], a1, 0, 0, 0);
+        for (int blk = 0; blk < NB; ++blk) x[blk] = xn[blk];
+#ifndef PM_ABL_NOLDSREAD
+        if (c + 1 < NCH) {
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk)
+                xn[blk] = *reinterpret_cast<const f32x4*>(tb + 32 * blk * LDT + 8 * (c + 1));
         }
+#endif
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk)
+                a[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[blk][t], qf[c][t], a[blk], 0, 0, 0);
+#ifndef PM_ABL_NOSTAGE
+        if (c == 0) st.load(T, tnorm, next_tile, nt, dim, tid);                       // global -> registers
+        if (c == NCH - 2) st.store(Ts, buf ^ 1, tid);                                 // registers -> LDS
+#endif
+#ifdef PM_ABL_NOEPI
+        if (false) {
+#else
         if (EPI) {
-            constexpr int PER = 32 / NCH;          // selection steps per chunk
+#endif
+            constexpr int PER = 16 * NB / NCH;      // selection steps per chunk
+            static_assert(16 * NB % NCH == 0, "selection must split evenly over the chunks");
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
-                const int v = c * PER + u;         // 0..31: block v>>4, register v&15
-                const float w = v < 16 ? p0[v & 15] : p1[v & 15];
-                top4_insert(cl, embed_lid(w, keep_mask, pbase | static_cast<unsigned>(v)));
+                const int v = c * PER + u;          // block v>>4, register v&15
+                top4_insert(cl, embed_lid(p[v >> 4][v & 15], keep_mask, pbase + static_cast<unsigned>(v)));
             }
             // pin the selection to this chunk: without a use here hipcc sinks all of it below the
-            // MFMA chain (in front of the barrier), where nothing hides it.  Placed after the
-            // chunk's MFMAs, the ~10 VALU ops issue in the shadow of the last 64-cycle MFMA.
+            // MFMA chain (in front of the barrier), where nothing hides it.
             asm volatile("" : "+v"(cl[0]), "+v"(cl[1]), "+v"(cl[2]), "+v"(cl[3]));
         }
     }
 }
 
-__device__ __forceinline__ void knn_select_all(const f32x16& p0, const f32x16& p1, unsigned pbase,
-                                               unsigned keep_mask, f32x4& cl)
+template <int NB>
+__device__ __forceinline__ void knn_select_all(const f32x16 (&p)[NB], unsigned pbase, unsigned keep_mask, f32x4& cl)
 {
 #pragma unroll
-    for (int v = 0; v < 32; ++v) {
-        const float w = v < 16 ? p0[v & 15] : p1[v & 15];
-        top4_insert(cl, embed_lid(w, keep_mask, pbase | static_cast<unsigned>(v)));
-    }
+    for (int v = 0; v < 16 * NB; ++v)
+        top4_insert(cl, embed_lid(p[v >> 4][v & 15], keep_mask, pbase + static_cast<unsigned>(v)));
 }
 
-template <int NCH, bool FULL>
-__global__ __launch_bounds__(256, 2) void knn_l2_mfma(
+#ifdef PM_ABL_NOBARRIER
+#define PM_TILE_BARRIER() asm volatile("" ::: "memory")
+#else
+#define PM_TILE_BARRIER() __syncthreads()
+#endif
+
+template <int NCH, bool FULL, int TT>
+__global__ __launch_bounds__(256, (TT == 64 ? 2 : 1)) void knn_l2_mfma(
     const float* __restrict__ Q, const float* __restrict__ T, const float* __restrict__ tnorm, int nq,
     int nt, int dim, int tiles_per_split, unsigned keep_mask, float* __restrict__ cand_val, int slots)
 {
-    using Tile = KnnTile<NCH, FULL>;
+    using Tile = KnnTile<NCH, FULL, TT>;
     constexpr int LDT = Tile::LDT;
+    constexpr int NB = TT / 32;
+    constexpr unsigned IDS = 16 * NB;          // row ids a lane sees per tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ts = smem;                          // [2][TILE_T][LDT]
-    float* Tn = smem + 2 * TILE_T * LDT;       // [2][TILE_T]
+    float* Ts = smem;                          // [2][TT][LDT], seed in each row's pad slot
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -319,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void knn_l2_mfma(
         qf[c] = v;
     }
 
-    const int ntiles = (nt + TILE_T - 1) / TILE_T;
+    const int ntiles = (nt + TT - 1) / TT;
     const int tile0 = blockIdx.y * tiles_per_split;
     int tile1 = tile0 + tiles_per_split;
     if (tile1 > ntiles) tile1 = ntiles;
@@ -328,43 +391,30 @@ __global__ __launch_bounds__(256, 2) void knn_l2_mfma(
     if (tile0 < tile1) {                       // block-uniform
         Tile st;
         st.load(T, tnorm, tile0, nt, dim, tid);
-        st.store(Ts, Tn, 0, tid);
+        st.store(Ts, 0, tid);
         __syncthreads();
 
-        // every accumulator has a compile-time name: tiles alternate A, B, A, ...
-        f32x16 accA0, accA1, accB0, accB1;
-        int tile = tile0;
-        {   // first tile -> A, nothing pending
-            const bool more = tile + 1 < tile1;
-            if (more) st.load(T, tnorm, tile + 1, nt, dim, tid);
-            knn_tile_compute<NCH, false>(Ts, Tn, 0, r, h, qf, accA0, accA1, accA0, accA1, 0u, keep_mask, cl);
-            if (more) st.store(Ts, Tn, 1, tid);
-            __syncthreads();
-            ++tile;
-        }
+        // every accumulator has a compile-time name: tiles alternate A, B, A, ...  (tix = tile - tile0)
+        f32x16 accA[NB], accB[NB];
+        int tix = 0;
+        const int ntl = tile1 - tile0;
+        knn_tile_compute<NCH, FULL, NB, false>(Ts, 0, r, h, qf, accA, accA, 0u, keep_mask, cl, st, T, tnorm,
+                                               tile0 + 1, nt, dim, tid);
+        PM_TILE_BARRIER();
+        ++tix;
         for (;;) {
-            if (tile >= tile1) { knn_select_all(accA0, accA1, static_cast<unsigned>(tile - 1 - tile0) << 5, keep_mask, cl); break; }
-            {   // tile -> B while selecting A (tile-1)
-                const int buf = (tile - tile0) & 1;
-                const bool more = tile + 1 < tile1;
-                if (more) st.load(T, tnorm, tile + 1, nt, dim, tid);
-                knn_tile_compute<NCH, true>(Ts, Tn, buf, r, h, qf, accB0, accB1, accA0, accA1,
-                                            static_cast<unsigned>(tile - 1 - tile0) << 5, keep_mask, cl);
-                if (more) st.store(Ts, Tn, buf ^ 1, tid);
-                __syncthreads();
-                ++tile;
-            }
-            if (tile >= tile1) { knn_select_all(accB0, accB1, static_cast<unsigned>(tile - 1 - tile0) << 5, keep_mask, cl); break; }
-            {   // tile -> A while selecting B (tile-1)
-                const int buf = (tile - tile0) & 1;
-                const bool more = tile + 1 < tile1;
-                if (more) st.load(T, tnorm, tile + 1, nt, dim, tid);
-                knn_tile_compute<NCH, true>(Ts, Tn, buf, r, h, qf, accA0, accA1, accB0, accB1,
-                                            static_cast<unsigned>(tile - 1 - tile0) << 5, keep_mask, cl);
-                if (more) st.store(Ts, Tn, buf ^ 1, tid);
-                __syncthreads();
-                ++tile;
-            }
+            if (tix >= ntl) { knn_select_all<NB>(accA, static_cast<unsigned>(tix - 1) * IDS, keep_mask, cl); break; }
+            // tile -> B while selecting A (tile-1)
+            knn_tile_compute<NCH, FULL, NB, true>(Ts, tix & 1, r, h, qf, accB, accA, static_cast<unsigned>(tix - 1) * IDS,
+                                                  keep_mask, cl, st, T, tnorm, tile0 + tix + 1, nt, dim, tid);
+            PM_TILE_BARRIER();
+            ++tix;
+            if (tix >= ntl) { knn_select_all<NB>(accB, static_cast<unsigned>(tix - 1) * IDS, keep_mask, cl); break; }
+            // tile -> A while selecting B (tile-1)
+            knn_tile_compute<NCH, FULL, NB, true>(Ts, tix & 1, r, h, qf, accA, accB, static_cast<unsigned>(tix - 1) * IDS,
+                                                  keep_mask, cl, st, T, tnorm, tile0 + tix + 1, nt, dim, tid);
+            PM_TILE_BARRIER();
+            ++tix;
         }
     }
 
@@ -390,12 +440,67 @@ __device__ __forceinline__ void best2_insert(Best2& b, uint64_t key, float d)
     }
 }
 
+// position of the r-th (0-based) set bit of m; r < popcount(m)
+__device__ __forceinline__ int nth_set_bit(unsigned long long m, int r)
+{
+    int pos = 0;
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) {
+        const int c = __popcll((m >> pos) & ((1ull << w) - 1ull));
+        if (r >= c) { r -= c; pos += w; }
+    }
+    return pos;
+}
+
+// SPEC S1 evaluated by 8 consecutive lanes: lane l (0..7) of the group IS accumulator l of the
+// canonical form (same products, same order), the combine uses the canonical association.  The
+// 16 loads per operand of a lane are independent, so one candidate costs about one memory round
+// trip instead of dim/8 dependent ones.  Result valid in the group's lane 0.
+__device__ __forceinline__ float l2sqr_canonical_coop8(const float* __restrict__ a, const float* __restrict__ b,
+                                                       int dim, int l)
+{
+    float acc = 0.f;
+    const int full8 = dim & ~7;
+    int j0 = 0;
+    // Blocks of 16 (then 8) column groups with NO per-element condition: all loads of a block are
+    // issued before the first subtraction.  (A guarded or clamped element makes hipcc wait for
+    // every pair of loads in turn: 16 dependent memory round trips per candidate.)
+    for (; j0 + 128 <= full8; j0 += 128) {
+        float av[16], bv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { av[u] = a[j0 + 8 * u + l]; bv[u] = b[j0 + 8 * u + l]; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const float t = av[u] - bv[u]; const float p = t * t; acc = acc + p; }
+    }
+    for (; j0 + 64 <= full8; j0 += 64) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { av[u] = a[j0 + 8 * u + l]; bv[u] = b[j0 + 8 * u + l]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const float t = av[u] - bv[u]; const float p = t * t; acc = acc + p; }
+    }
+    for (; j0 < full8; j0 += 8) {
+        const float t = a[j0 + l] - b[j0 + l];
+        const float p = t * t;
+        acc = acc + p;
+    }
+    const float s = acc + __shfl_down(acc, 4, 8);            // lanes 0..3: acc[l] + acc[l+4]
+    const float s1 = __shfl_down(s, 1, 8), s2 = __shfl_down(s, 2, 8), s3 = __shfl_down(s, 3, 8);
+    float d = ((s + s1) + s2) + s3;                          // meaningful in lane 0
+    for (int j = full8; j < dim; ++j) {
+        const float t = a[j] - b[j];
+        const float p = t * t;
+        d = d + p;
+    }
+    return d;
+}
+
 template <bool VEC4>
 __global__ __launch_bounds__(256) void knn_l2_refine(
     const float* __restrict__ Q, const float* __restrict__ T, const float* __restrict__ qnorm,
     const unsigned long long* __restrict__ stats, unsigned epoch, unsigned* __restrict__ diag, int nq, int nt,
-    int dim, int k, int slots, const float* __restrict__ cand_val, int tiles_per_split, unsigned lid_mask,
-    float eps_coef, float embed_coef, pm_match* __restrict__ out)
+    int dim, int k, int slots, const float* __restrict__ cand_val, int tiles_per_split, int rows_per_tile,
+    unsigned lid_mask, float eps_coef, float embed_coef, pm_match* __restrict__ out)
 {
     const int lane = threadIdx.x & 63;
     const int q = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -416,9 +521,10 @@ __global__ __launch_bounds__(256) void knn_l2_refine(
     auto row_of = [&](int s) -> int {
         const unsigned lid = __float_as_uint(cv[s]) & lid_mask;
         const int split = s / (2 * KNN_C), hh = (s / KNN_C) & 1;
-        const int reg = lid & 15, blk = (lid >> 4) & 1;
-        return (split * tiles_per_split + static_cast<int>(lid >> 5)) * TILE_T + 32 * blk + (reg & 3) +
-               8 * (reg >> 2) + 4 * hh;
+        const int ids_shift = 31 - __clz(rows_per_tile >> 1);                   // ids per tile = rows/2 = 2^shift
+        const int tile = static_cast<int>(lid >> ids_shift), rem = static_cast<int>(lid & ((1u << ids_shift) - 1u));
+        const int reg = rem & 15, blk = rem >> 4;
+        return (split * tiles_per_split + tile) * rows_per_tile + 32 * blk + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
     };
 
     // k-th smallest coarse value over all slots (k <= 2)
@@ -437,22 +543,52 @@ __global__ __launch_bounds__(256) void knn_l2_refine(
     }
     const float thr = (tau + eps) * 1.00000095367431640625f + eps;
 
-    // a sub-list whose largest kept entry is inside the window may have dropped candidates
-    bool spill = false;
-    for (int s = lane; s < slots; s += 64)
-        if ((s & (KNN_C - 1)) == KNN_C - 1) spill |= coarse(s) <= thr;
-    const bool rescan = nonfinite || !(thr < KNN_INF) || __any(spill);
+    // Non-finite inputs (or a window that is not finite) void the coarse ranking: scan everything.
+    const bool rescan = nonfinite || !(thr < KNN_INF);
     if (diag && lane == 0) { if (rescan) atomicAdd(&diag[0], 1u); if (nonfinite) diag[1] = 1u; }
 
     Best2 b{~0ull, ~0ull, KNN_INF, KNN_INF};
     if (!rescan) {
-        for (int s = lane; s < slots; s += 64) {
-            const float v = coarse(s);
-            const int j = row_of(s);
-            if (v <= thr && j < nt) {
-                const float d = __builtin_sqrtf(
-                    l2sqr_canonical<VEC4>(qp, T + static_cast<size_t>(j) * dim, dim));
-                best2_insert(b, knn_key(d, j), d);
+        const int grp = lane >> 3, l = lane & 7;
+        const int ids = rows_per_tile >> 1;                 // row ids a lane sees per tile (a power of two)
+        const int ids_shift2 = 31 - __clz(ids);
+        for (int base = 0; base < slots; base += 64) {
+            const int s = base + lane;
+            const bool in = s < slots;
+            const float v = in ? coarse(s) : KNN_INF;
+            const int j = in ? row_of(s) : 0;
+            // a sub-list (4 consecutive slots) whose 4th entry is inside the window may have
+            // dropped candidates: its rows are scanned below instead of trusting its slots
+            unsigned long long spilled = __ballot(in && (s & (KNN_C - 1)) == KNN_C - 1 && v <= thr);
+            const bool mine_spilled = (spilled >> (lane | (KNN_C - 1))) & 1ull;
+            const unsigned long long cand = __ballot(in && v <= thr && j < nt && !mine_spilled);
+            const int nc = __popcll(cand);
+            for (int r0 = 0; r0 < nc; r0 += 8) {           // 8 candidates per round, 8 lanes each
+                const int rank = r0 + grp;
+                const bool live = rank < nc;
+                const int src = nth_set_bit(cand, live ? rank : 0);
+                const int jj = __shfl(j, src, 64);
+                const float d2 = l2sqr_canonical_coop8(qp, T + static_cast<size_t>(jj) * dim, dim, l);
+                if (live && l == 0) {
+                    const float d = __builtin_sqrtf(d2);
+                    best2_insert(b, knn_key(d, jj), d);
+                }
+            }
+            if (diag && lane == 0 && spilled) atomicAdd(&diag[0], static_cast<unsigned>(__popcll(spilled)));
+            while (spilled) {                               // wave-uniform
+                const int sub = (base + __ffsll(static_cast<long long>(spilled)) - 1) / KNN_C;
+                spilled &= spilled - 1ull;
+                const int split = sub >> 1, hh = sub & 1;
+                for (int lid = lane; lid < tiles_per_split * ids; lid += 64) {
+                    const int tile = lid >> ids_shift2, rem = lid & (ids - 1);
+                    const int row = (split * tiles_per_split + tile) * rows_per_tile + 32 * (rem >> 4) + (rem & 3) +
+                                    8 * ((rem & 15) >> 2) + 4 * hh;
+                    if (row < nt) {
+                        const float d = __builtin_sqrtf(
+                            l2sqr_canonical<VEC4>(qp, T + static_cast<size_t>(row) * dim, dim));
+                        best2_insert(b, knn_key(d, row), d);
+                    }
+                }
             }
         }
     } else {
@@ -671,21 +807,21 @@ __global__ __launch_bounds__(256) void knn_l2_exact(const float* __restrict__ Q,
     }
 }
 
-template <int NCH, bool FULL>
+template <int NCH, bool FULL, int TT>
 int launch_mfma(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt, int dim,
                 const float* tnorm, int splits, int tiles_per_split, unsigned keep_mask, float* cval, int slots)
 {
     constexpr int LDT = NCH * 8 + 4;
-    const size_t lds = (2 * TILE_T * LDT + 2 * TILE_T) * sizeof(float);
+    const size_t lds = 2 * TT * LDT * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        PM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_l2_mfma<NCH, FULL>),
+        PM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_l2_mfma<NCH, FULL, TT>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
         attr_done = true;
     }
     dim3 grid((nq + QB - 1) / QB, splits);
     pm::ScopedKernelTime t(ctx, "knn_l2_mfma");
-    hipLaunchKernelGGL((knn_l2_mfma<NCH, FULL>), grid, dim3(256), lds, ctx->stream, dq, dt, tnorm, nq, nt, dim,
+    hipLaunchKernelGGL((knn_l2_mfma<NCH, FULL, TT>), grid, dim3(256), lds, ctx->stream, dq, dt, tnorm, nq, nt, dim,
                        tiles_per_split, keep_mask, cval, slots);
     PM_HIP_CHECK(hipGetLastError());
     return PM_OK;
@@ -722,19 +858,22 @@ extern "C" int pm_bf_knn_l2_f32_dev(pm_ctx* ctx, const float* dq, int nq, const 
     const bool fast = !(flags & PM_KNN_FORCE_EXACT) && k <= 2 && (dim % 4) == 0 && dim <= 128 && nt >= 1;
     if (!fast) return run_exact(ctx, dq, nq, dt, nt, dim, k, dout);
 
-    // split the train rows so that the grid fills the chip (~2 workgroups per CU)
-    const int ntiles = (nt + TILE_T - 1) / TILE_T;
+    // tile height: 64 rows = two workgroups (8 waves) per CU.  (A 128-row tile with one workgroup
+    // per CU measured 172 us against 153 us at C3, so the kernel is instantiated for 64 only.)
     const int nqb = (nq + QB - 1) / QB;
-    int splits = (2 * ctx->n_cu + nqb - 1) / nqb;
+    constexpr int TT = 64;
+    // split the train rows so that the grid fills the chip (TT=64: ~2 workgroups per CU, 128: ~1)
+    const int ntiles = (nt + TT - 1) / TT;
+    int splits = ((TT == 64 ? 2 : 1) * ctx->n_cu + nqb - 1) / nqb;
     if (splits > ntiles) splits = ntiles;
     if (splits > 64) splits = 64;
     if (splits < 1) splits = 1;
     const int tiles_per_split = (ntiles + splits - 1) / splits;
     splits = (ntiles + tiles_per_split - 1) / tiles_per_split;
     const int slots = splits * 2 * KNN_C;
-    // row id inside a lane's stream: tile_in_split*32 + block*16 + reg, in the low mantissa bits
+    // row id inside a lane's stream: tile_in_split*(TT/2) + block*16 + reg, in the low mantissa bits
     int lid_bits = 5;
-    while ((1 << lid_bits) < tiles_per_split * 32) ++lid_bits;
+    while ((1 << lid_bits) < tiles_per_split * (TT / 2)) ++lid_bits;
     if (lid_bits > 16) return run_exact(ctx, dq, nq, dt, nt, dim, k, dout);     // > 2048 tiles per split
     const unsigned lid_mask = (1u << lid_bits) - 1u;
 
@@ -768,7 +907,7 @@ extern "C" int pm_bf_knn_l2_f32_dev(pm_ctx* ctx, const float* dq, int nq, const 
         PM_HIP_CHECK(hipGetLastError());
     }
 #define PM_LAUNCH_MFMA(NCH_, FULL_) \
-    launch_mfma<NCH_, FULL_>(ctx, dq, nq, dt, nt, dim, tnorm, splits, tiles_per_split, ~lid_mask, cval, slots)
+    launch_mfma<NCH_, FULL_, TT>(ctx, dq, nq, dt, nt, dim, tnorm, splits, tiles_per_split, ~lid_mask, cval, slots)
     if (dim == 128) rc = PM_LAUNCH_MFMA(16, true);
     else if (dim == 64) rc = PM_LAUNCH_MFMA(8, true);
     else if (dim == 32) rc = PM_LAUNCH_MFMA(4, true);
@@ -785,8 +924,8 @@ extern "C" int pm_bf_knn_l2_f32_dev(pm_ctx* ctx, const float* dq, int nq, const 
     {
         pm::ScopedKernelTime t(ctx, "knn_l2_refine");
         hipLaunchKernelGGL(knn_l2_refine<true>, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, dq, dt, qnorm, stats,
-                           epoch, diag, nq, nt, dim, k, slots, cval, tiles_per_split, lid_mask, eps_coef, embed_coef,
-                           dout);
+                           epoch, diag, nq, nt, dim, k, slots, cval, tiles_per_split, TT, lid_mask, eps_coef,
+                           embed_coef, dout);
         PM_HIP_CHECK(hipGetLastError());
     }
     return PM_OK;

@@ -166,6 +166,7 @@ int pm_ctx_destroy(pm_ctx* ctx)
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->knn_stats) (void)hipFree(ctx->knn_stats);
+    if (ctx->fg_counts) (void)hipFree(ctx->fg_counts);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;

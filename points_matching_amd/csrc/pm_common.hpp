@@ -65,6 +65,9 @@ struct pm_ctx {
     unsigned* knn_diag_words = nullptr;
     unsigned knn_epoch = 0;
     bool knn_diag = false;
+    // stable compaction: epoch-tagged per-block survivor counts
+    unsigned* fg_counts = nullptr;
+    unsigned fg_epoch = 0;
 };
 
 namespace pm {

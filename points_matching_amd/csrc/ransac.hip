@@ -94,7 +94,9 @@ __device__ __forceinline__ void jacobi_pair(double (&G)[3][3], double (&V)[3][3]
     double al = G[0][P] * G[0][P]; al = fma(G[1][P], G[1][P], al); al = fma(G[2][P], G[2][P], al);
     double be = G[0][Qc] * G[0][Qc]; be = fma(G[1][Qc], G[1][Qc], be); be = fma(G[2][Qc], G[2][Qc], be);
     double ga = G[0][P] * G[0][Qc]; ga = fma(G[1][P], G[1][Qc], ga); ga = fma(G[2][P], G[2][Qc], ga);
-    if (ga == 0.0 || ga != ga) return;
+    // converged pair: |ga| <= 2^-52 * sqrt(al*be), tested without the root.  Same bits on both
+    // sides, so the skip is deterministic; late sweeps then cost three dot products per pair.
+    if (!(ga * ga > 4.930380657631324e-32 * (al * be))) return;
     const double zeta = (be - al) / (2.0 * ga);
     const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(fma(zeta, zeta, 1.0)));
     const double c = 1.0 / sqrt(fma(t, t, 1.0));
@@ -296,12 +298,46 @@ __global__ __launch_bounds__(64) void ransac_solve(const float* __restrict__ xy1
     for (int i = 0; i < 9; ++i) m64[i] = F[i];
 }
 
+constexpr int SCORE_CHUNK = 256;      // correspondences staged per workgroup (4 KB of LDS)
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// SPEC S8 on TWO correspondences at once: every operation is the packed-f32 form of the scalar
+// one (v_pk_fma_f32 / v_pk_mul_f32 are IEEE per component, so the bits equal inlier32), which
+// halves the VALU issue slots of the scorer.  Returns how many of the two are inliers.
+template <int KIND>
+__device__ __forceinline__ int inlier32_x2(const float (&f)[9], f32x2 x, f32x2 y, f32x2 xp, f32x2 yp, float thr2)
+{
+#define PM_SPLAT(v) f32x2{(v), (v)}
+    const f32x2 a = __builtin_elementwise_fma(PM_SPLAT(f[0]), x, __builtin_elementwise_fma(PM_SPLAT(f[1]), y, PM_SPLAT(f[2])));
+    const f32x2 b = __builtin_elementwise_fma(PM_SPLAT(f[3]), x, __builtin_elementwise_fma(PM_SPLAT(f[4]), y, PM_SPLAT(f[5])));
+    const f32x2 c = __builtin_elementwise_fma(PM_SPLAT(f[6]), x, __builtin_elementwise_fma(PM_SPLAT(f[7]), y, PM_SPLAT(f[8])));
+    const f32x2 num = __builtin_elementwise_fma(xp, a, __builtin_elementwise_fma(yp, b, c));
+    const f32x2 at = __builtin_elementwise_fma(PM_SPLAT(f[0]), xp, __builtin_elementwise_fma(PM_SPLAT(f[3]), yp, PM_SPLAT(f[6])));
+    const f32x2 bt = __builtin_elementwise_fma(PM_SPLAT(f[1]), xp, __builtin_elementwise_fma(PM_SPLAT(f[4]), yp, PM_SPLAT(f[7])));
+    const f32x2 n2 = num * num;
+    const f32x2 t2 = PM_SPLAT(thr2);
+#undef PM_SPLAT
+    if (KIND == PM_ERR_SAMPSON) {
+        const f32x2 den = __builtin_elementwise_fma(a, a, __builtin_elementwise_fma(b, b, __builtin_elementwise_fma(at, at, bt * bt)));
+        const f32x2 rhs = t2 * den;
+        return (n2[0] <= rhs[0] ? 1 : 0) + (n2[1] <= rhs[1] ? 1 : 0);
+    } else {
+        const f32x2 r2 = t2 * __builtin_elementwise_fma(a, a, b * b);
+        const f32x2 r1 = t2 * __builtin_elementwise_fma(at, at, bt * bt);
+        return ((n2[0] <= r2[0]) && (n2[0] <= r1[0]) ? 1 : 0) + ((n2[1] <= r2[1]) && (n2[1] <= r1[1]) ? 1 : 0);
+    }
+}
+
 template <int KIND>
 __global__ __launch_bounds__(256) void ransac_score(const float* __restrict__ xy1, const float* __restrict__ xy2,
                                                     int n_max, const int* __restrict__ d_n, int chunk_len,
                                                     const float* __restrict__ models, int nh, float thr2,
                                                     int* __restrict__ counts)
 {
+    // pair p of the chunk: pts[2p] = (x_a, x_b, y_a, y_b), pts[2p+1] = (x'_a, x'_b, y'_a, y'_b)
+    __shared__ __attribute__((aligned(16))) float pts[SCORE_CHUNK * 4];
     const int n = resolve_n(n_max, d_n);
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int tl = t < nh ? t : nh - 1;
@@ -312,11 +348,38 @@ __global__ __launch_bounds__(256) void ransac_score(const float* __restrict__ xy
     const int i0 = blockIdx.y * chunk_len;
     int i1 = i0 + chunk_len;
     if (i1 > n) i1 = n;
+    const int len = i1 - i0;                    // <= SCORE_CHUNK, may be <= 0 past the device count
+    const int len2 = (len + 1) & ~1;
+    // one coalesced pass into LDS; every lane then reads the same address (broadcast), so a pair of
+    // points costs two ds_read_b128 per wave.  An odd tail is padded with NaN (never an inlier).
+    {
+        const int tt = threadIdx.x;
+        if (tt < len2) {
+            float2 p = {__builtin_nanf(""), __builtin_nanf("")}, pp = p;
+            if (tt < len) {
+                p = *reinterpret_cast<const float2*>(xy1 + 2 * static_cast<size_t>(i0 + tt));
+                pp = *reinterpret_cast<const float2*>(xy2 + 2 * static_cast<size_t>(i0 + tt));
+            }
+            float* d = pts + (tt >> 1) * 8 + (tt & 1);
+            d[0] = p.x; d[2] = p.y; d[4] = pp.x; d[6] = pp.y;
+        }
+    }
+    __syncthreads();
     int cnt = 0;
-    for (int i = i0; i < i1; ++i) {
-        const float2 p = *reinterpret_cast<const float2*>(xy1 + 2 * static_cast<size_t>(i));   // wave-uniform
-        const float2 pp = *reinterpret_cast<const float2*>(xy2 + 2 * static_cast<size_t>(i));
-        cnt += inlier32<KIND>(f, p.x, p.y, pp.x, pp.y, thr2) ? 1 : 0;
+    const int npair = len2 >> 1;
+    int p = 0;
+    for (; p + 2 <= npair; p += 2) {
+        const f32x4v u0 = *reinterpret_cast<const f32x4v*>(pts + p * 8);
+        const f32x4v v0 = *reinterpret_cast<const f32x4v*>(pts + p * 8 + 4);
+        const f32x4v u1 = *reinterpret_cast<const f32x4v*>(pts + p * 8 + 8);
+        const f32x4v v1 = *reinterpret_cast<const f32x4v*>(pts + p * 8 + 12);
+        cnt += inlier32_x2<KIND>(f, f32x2{u0[0], u0[1]}, f32x2{u0[2], u0[3]}, f32x2{v0[0], v0[1]}, f32x2{v0[2], v0[3]}, thr2);
+        cnt += inlier32_x2<KIND>(f, f32x2{u1[0], u1[1]}, f32x2{u1[2], u1[3]}, f32x2{v1[0], v1[1]}, f32x2{v1[2], v1[3]}, thr2);
+    }
+    for (; p < npair; ++p) {
+        const f32x4v u0 = *reinterpret_cast<const f32x4v*>(pts + p * 8);
+        const f32x4v v0 = *reinterpret_cast<const f32x4v*>(pts + p * 8 + 4);
+        cnt += inlier32_x2<KIND>(f, f32x2{u0[0], u0[1]}, f32x2{u0[2], u0[3]}, f32x2{v0[0], v0[1]}, f32x2{v0[2], v0[3]}, thr2);
     }
     if (t < nh && cnt) atomicAdd(&counts[t], cnt);
 }
@@ -393,15 +456,15 @@ __global__ __launch_bounds__(1024) void ransac_pick(const float* __restrict__ mo
 {
     __shared__ unsigned long long wbest[16];
     unsigned long long key = 0ull;
-    for (int t0 = threadIdx.x; t0 < nh; t0 += 4 * 1024) {
-        unsigned long long k4[4];
+    for (int t0 = threadIdx.x; t0 < nh; t0 += 12 * 1024) {          // 12 independent load pairs per trip
+        unsigned long long kk[12];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 12; ++u) {
             const int t = t0 + u * 1024;
-            k4[u] = hyp_key(models, counts, t < nh ? t : nh - 1, hyp_begin);   // clamped: a duplicate is harmless
+            kk[u] = hyp_key(models, counts, t < nh ? t : nh - 1, hyp_begin);   // clamped: a duplicate is harmless
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) key = k4[u] > key ? k4[u] : key;
+        for (int u = 0; u < 12; ++u) key = kk[u] > key ? kk[u] : key;
     }
     key = wave_max_u64(key);
     if ((threadIdx.x & 63) == 0) wbest[threadIdx.x >> 6] = key;
@@ -515,11 +578,13 @@ int score_shard(pm_ctx* ctx, const float* dxy1, const float* dxy2, int n, const 
     const int hb = (nh + 255) / 256;
     int chunks = (8 * ctx->n_cu + hb - 1) / hb;
     const int max_chunks = (n + 15) / 16;
+    const int min_chunks = (n + SCORE_CHUNK - 1) / SCORE_CHUNK;          // a chunk must fit the LDS stage
     if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks < min_chunks) chunks = min_chunks;
     if (chunks < 1) chunks = 1;
-    if (chunks > 65535) chunks = 65535;
     const int chunk_len = (n + chunks - 1) / chunks;
     chunks = (n + chunk_len - 1) / chunk_len;
+    PM_REQUIRE(chunks <= 65535, PM_E_UNSUPPORTED, "more than 16.7M correspondences per RANSAC call");
     const float thr2 = p->thresh_px * p->thresh_px;
     {
         pm::ScopedKernelTime t(ctx, "ransac_score");

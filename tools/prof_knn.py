@@ -26,7 +26,12 @@ d_q = torch.from_numpy(w["q"]).to(dev)
 d_t = torch.from_numpy(w["t"]).to(dev)
 d_out = torch.empty((nq, 2, 4), dtype=torch.int32, device=dev)
 torch.cuda.synchronize()
+for _ in range(3):
+    ctx.bf_knn_l2_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, 2, d_out.data_ptr())
+ctx.timing_enable(True)
+ctx.timing_reset()
 for _ in range(reps):
     ctx.bf_knn_l2_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, 2, d_out.data_ptr())
 torch.cuda.synchronize()
-print("done", nq, nt, dim, reps)
+print("done", nq, nt, dim, reps, os.environ.get("PM_LIB_PATH", "default"),
+      {k: round(ctx.timing_get(k)[0] * 1e3, 1) for k in ("knn_l2_prep", "knn_l2_mfma", "knn_l2_refine")})
