@@ -88,11 +88,18 @@ int  pm_version(void);                 /* major*100 + minor */
  *      smaller distance first, equal distances -> lower trainIdx first (SPEC S3).
  *      If nt < k the tail of each row has trainIdx = -1, distance = +inf.
  * 1 <= k <= PM_MAX_K.  nq == 0 is ok (no output).  nt == 0 gives all -1 rows.
- * `flags`: 0 = automatic (MFMA coarse pass + canonical refinement when dim%8==0 && dim<=128 &&
- *          k<=2, exact kernel otherwise); PM_KNN_FORCE_EXACT = always the exact VALU kernel.
- *          Both produce bit-identical output (tests assert it). */
+ * `flags`: 0 = automatic.  For dim%4==0 && dim<=128 && k<=2: MFMA coarse pass + canonical
+ *          refinement; the coarse pass is the exact f16-MFMA route when the data are integer-valued
+ *          (decided on the device, no host round trip: both coarse kernels are enqueued and the one
+ *          that does not apply exits at once) and the f32-MFMA route otherwise.  Anything else:
+ *          exact VALU kernel.  All routes produce bit-identical output (tests assert it). */
 #define PM_MAX_K 16
-#define PM_KNN_FORCE_EXACT 1
+#define PM_KNN_FORCE_EXACT  1   /* exact VALU kernel only                                           */
+#define PM_KNN_FORCE_F32    2   /* f32-MFMA coarse route only (any finite floats)                   */
+#define PM_KNN_HINT_INTEGER 4   /* caller states the descriptors are integer-valued with |x| <= 361 */
+                                /* (OpenCV SIFT: 0..255): only the exact f16-MFMA coarse route is   */
+                                /* launched.  The claim is verified on the device; a wrong hint     */
+                                /* costs time (exact re-scan), never correctness.                   */
 int pm_bf_knn_l2_f32(pm_ctx* ctx, const float* q, int nq, const float* t, int nt,
                      int dim, int k, int flags, pm_match* out);
 int pm_bf_knn_l2_f32_dev(pm_ctx* ctx, const float* d_q, int nq, const float* d_t, int nt,

@@ -354,8 +354,13 @@ __device__ __forceinline__ void knn_select_all(const f32x16 (&p)[NB], unsigned p
 template <int NCH, bool FULL, int TT>
 __global__ __launch_bounds__(256, (TT == 64 ? 2 : 1)) void knn_l2_mfma(
     const float* __restrict__ Q, const float* __restrict__ T, const float* __restrict__ tnorm, int nq,
-    int nt, int dim, int tiles_per_split, unsigned keep_mask, float* __restrict__ cand_val, int slots)
+    int nt, int dim, int tiles_per_split, unsigned keep_mask, float* __restrict__ cand_val, int slots,
+    const unsigned long long* __restrict__ stats, unsigned epoch, int only_if_ineligible)
 {
+    if (only_if_ineligible) {                  // auto mode: the f16 route handles eligible data
+        const unsigned long long s1 = stats[1];
+        if (!(static_cast<unsigned>(s1 >> 32) == epoch && (s1 & 2ull))) return;
+    }
     using Tile = KnnTile<NCH, FULL, TT>;
     constexpr int LDT = Tile::LDT;
     constexpr int NB = TT / 32;
@@ -425,6 +430,244 @@ __global__ __launch_bounds__(256, (TT == 64 ? 2 : 1)) void knn_l2_mfma(
 }
 
 // ---------------------------------------------------------------------------------------------
+// f16 route: integer-valued descriptors (what OpenCV's SIFT emits: 0..255 stored as float)
+//
+// For integer data with dim * max|x|^2 < 2^24 every product and every partial sum of q.t is an
+// integer below 2^24, so v_mfma_f32_32x32x16_f16 (f16 operands, f32 accumulate) computes the dot
+// product EXACTLY at 16x the f32 matrix rate.  knn_l2_prep16 writes f16 copies of both matrices in
+// rows of H_ROW = 128 data halfs (zero padded) + one 16-half chunk that carries the row seed
+// through the matrix pipe:   train row : (A2, A1, A0, 0, ...),  ||t||^2 = 8192*A2 + 64*A1 + A0
+//                            query row : (-4096, -32, -0.5, 0, ...)
+// so the ninth k-chunk contributes exactly -||t||^2/2 and the accumulator ends as
+// w = q.t - ||t||^2/2 with no VALU work.  The copies are padded to whole tiles (pad train rows
+// carry A2 = 60000, i.e. w << any real row), which removes every bounds check from the kernel.
+// prep16 also VERIFIES the premise on the device (integers, |x| <= 361, finite): if it fails, bit 1
+// of stats[1] is raised and this route's result is not used (auto mode: the f32 kernel runs
+// instead; hint mode: the refinement re-scans exactly).  Wrong data costs time, never correctness.
+//
+// At this matrix rate the selection (5 VALU per pair) is as expensive as the MFMAs (8 per
+// 32x32 block = 256 cycles vs 16 values x 5 VALU per lane), so the kernel is organised around it:
+// a wave owns 64 queries (two B blocks: every A fragment read from LDS feeds two MFMAs), walks
+// the 128-row tile one 32-row block at a time and selects block b-1 (32 values per lane) between
+// the MFMAs of block b, with two alternating accumulator sets.
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int H_DP = 128;               // data columns
+constexpr int H_ROW = H_DP + 16;        // halfs per global row (288 B)
+constexpr int H_LDS_ROW = H_ROW + 8;    // halfs per LDS row (304 B: 16 rows of a lane group hit 16 slots)
+constexpr int H_NCH = H_ROW / 16;       // 9 k-chunks of 16
+constexpr int H_TT = 128;               // train rows per tile
+constexpr int H_QB = 256;               // queries per workgroup (4 waves x 64)
+constexpr float H_MAXABS = 361.f;       // 128 * 361^2 < 2^24
+
+__global__ __launch_bounds__(256) void knn_l2_prep16(const float* __restrict__ Q, int nq, int nq_pad,
+                                                     const float* __restrict__ T, int nt, int nt_pad, int dim,
+                                                     float* __restrict__ qnorm, float* __restrict__ tnorm,
+                                                     _Float16* __restrict__ Qh, _Float16* __restrict__ Th,
+                                                     unsigned long long* __restrict__ stats, unsigned epoch)
+{
+    __shared__ unsigned wmax[4];
+    __shared__ unsigned wbad[4];
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int qblocks = nq_pad / 64;
+    const bool is_t = static_cast<int>(blockIdx.x) >= qblocks;
+    const float* x = is_t ? T : Q;
+    const int n = is_t ? nt : nq;
+    float* norm = is_t ? tnorm : qnorm;
+    _Float16* xh = is_t ? Th : Qh;
+    const int row0 = (is_t ? blockIdx.x - qblocks : blockIdx.x) * 64;
+    unsigned mx = 0u, bad = 0u;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = row0 + it * 16 + grp;                 // < n_pad by construction
+        const bool live = row < n;
+        const float* p = x + static_cast<size_t>(live ? row : 0) * dim;
+        const int c0 = 8 * sub;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e += 4) {
+            f32x4 u = {0.f, 0.f, 0.f, 0.f};
+            if (live && c0 + e < dim) u = *reinterpret_cast<const f32x4*>(p + c0 + e);   // dim % 4 == 0
+            v[e] = u[0]; v[e + 1] = u[1]; v[e + 2] = u[2]; v[e + 3] = u[3];
+        }
+        float s = 0.f;
+        bool okrow = true;
+        f16x8 hv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s = fmaf(v[e], v[e], s);
+            okrow &= (v[e] == __builtin_rintf(v[e])) && (__builtin_fabsf(v[e]) <= H_MAXABS);
+            hv[e] = static_cast<_Float16>(v[e]);
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
+        if (!okrow) bad |= 2u;
+        *reinterpret_cast<f16x8*>(xh + static_cast<size_t>(row) * H_ROW + c0) = hv;
+        if (sub == 0) {
+            if (live) {
+                norm[row] = s;
+                if (!(s < KNN_INF)) bad |= 3u;
+                else if (is_t) mx = max(mx, f32_bits(s));
+            }
+            f16x8 e0 = {0, 0, 0, 0, 0, 0, 0, 0};
+            const f16x8 e1 = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (is_t) {
+                if (live) {
+                    const unsigned tn = s < 16777216.f ? static_cast<unsigned>(s) : 0u;   // exact when eligible
+                    e0[0] = static_cast<_Float16>(static_cast<float>(tn >> 13));
+                    e0[1] = static_cast<_Float16>(static_cast<float>((tn >> 6) & 127u));
+                    e0[2] = static_cast<_Float16>(static_cast<float>(tn & 63u));
+                } else {
+                    e0[0] = static_cast<_Float16>(60000.f);                               // pad row: w ~ -2.4e8
+                }
+            } else {
+                e0[0] = static_cast<_Float16>(-4096.f);
+                e0[1] = static_cast<_Float16>(-32.f);
+                e0[2] = static_cast<_Float16>(-0.5f);
+            }
+            *reinterpret_cast<f16x8*>(xh + static_cast<size_t>(row) * H_ROW + H_DP) = e0;
+            *reinterpret_cast<f16x8*>(xh + static_cast<size_t>(row) * H_ROW + H_DP + 8) = e1;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mx = max(mx, static_cast<unsigned>(__shfl_xor(static_cast<int>(mx), o, 64)));
+        bad |= static_cast<unsigned>(__shfl_xor(static_cast<int>(bad), o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { wmax[threadIdx.x >> 6] = mx; wbad[threadIdx.x >> 6] = bad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+        bad = wbad[0] | wbad[1] | wbad[2] | wbad[3];
+        const unsigned long long tag = static_cast<unsigned long long>(epoch) << 32;
+        if (is_t) atomicMax(&stats[0], tag | mx);
+        // stats[1] is a max, so the flags are published as the values 1 (non-finite), 2 (not
+        // f16-eligible) or 3 (both): 3 >= 2 >= 1 keeps "not eligible" visible once any block saw it,
+        // and a non-finite input is never eligible.
+        if (bad) atomicMax(&stats[1], tag | static_cast<unsigned long long>(bad == 1u ? 3u : bad));
+    }
+}
+
+// a tile = 128 rows x 288 B = 2304 x 16 B: nine 16-byte pieces per thread, staged through registers
+struct HTile {
+    static constexpr int PIECES = H_TT * (H_ROW / 8) / 256;
+    static_assert(H_TT * (H_ROW / 8) % 256 == 0, "tile must split evenly over the workgroup");
+    uint4 stg[PIECES];
+    __device__ __forceinline__ void load(const _Float16* __restrict__ Th, int tile, int tid)
+    {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int f = tid + 256 * i;
+            const int row = f / (H_ROW / 8), c8 = f % (H_ROW / 8);
+            stg[i] = *reinterpret_cast<const uint4*>(Th + static_cast<size_t>(tile * H_TT + row) * H_ROW + 8 * c8);
+        }
+    }
+    __device__ __forceinline__ void store(_Float16* __restrict__ hsm, int buf, int tid) const
+    {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int f = tid + 256 * i;
+            const int row = f / (H_ROW / 8), c8 = f % (H_ROW / 8);
+            *reinterpret_cast<uint4*>(hsm + (buf * H_TT + row) * H_LDS_ROW + 8 * c8) = stg[i];
+        }
+    }
+};
+
+// keep the 4 largest of this lane's stream for one of its two query columns
+__device__ __forceinline__ void h_select(const f32x16& acc, unsigned keep_mask, unsigned lidbase, f32x4& cl, int v0,
+                                         int v1)
+{
+#pragma unroll
+    for (int v = v0; v < v1; ++v) top4_insert(cl, embed_lid(acc[v], keep_mask, lidbase + static_cast<unsigned>(v)));
+}
+
+// one 32-row block of the tile: 9 k-chunks x 2 query blocks = 18 MFMAs, selecting the previous
+// block's accumulators (p0/p1, row-id base pbase) in between
+template <bool EPI>
+__device__ __forceinline__ void h_block(const _Float16* __restrict__ tb, const f16x8 (&qf)[2][H_NCH], f32x16& a0,
+                                        f32x16& a1, const f32x16& p0, const f32x16& p1, unsigned pbase,
+                                        unsigned keep_mask, f32x4 (&cl)[2])
+{
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f16x8 xn = *reinterpret_cast<const f16x8*>(tb);
+#pragma unroll
+    for (int c = 0; c < H_NCH; ++c) {
+        const f16x8 x = xn;
+        if (c + 1 < H_NCH) xn = *reinterpret_cast<const f16x8*>(tb + 16 * (c + 1));
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, qf[0][c], c == 0 ? zero : a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, qf[1][c], c == 0 ? zero : a1, 0, 0, 0);
+        if (EPI && c < 8) {                       // 32 values over the first 8 chunks: 2 per query column
+            h_select(p0, keep_mask, pbase, cl[0], 2 * c, 2 * c + 2);
+            h_select(p1, keep_mask, pbase, cl[1], 2 * c, 2 * c + 2);
+            asm volatile("" : "+v"(cl[0][0]), "+v"(cl[0][1]), "+v"(cl[0][2]), "+v"(cl[0][3]), "+v"(cl[1][0]),
+                         "+v"(cl[1][1]), "+v"(cl[1][2]), "+v"(cl[1][3]));
+        }
+    }
+}
+
+// mode: 0 = run always (hint), 1 = run only if prep16 found the data eligible (auto)
+__global__ __launch_bounds__(256, 2) void knn_l2_mfma_f16(const _Float16* __restrict__ Qh,
+                                                          const _Float16* __restrict__ Th, int nq, int nt,
+                                                          int tiles_per_split, unsigned keep_mask,
+                                                          float* __restrict__ cand_val, int slots,
+                                                          const unsigned long long* __restrict__ stats,
+                                                          unsigned epoch, int mode)
+{
+    if (mode == 1) {
+        const unsigned long long s1 = stats[1];
+        if (static_cast<unsigned>(s1 >> 32) == epoch && (s1 & 2ull)) return;      // f32 route takes over
+    }
+    extern __shared__ __attribute__((aligned(16))) _Float16 hsm[];                // [2][H_TT][H_LDS_ROW]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int qbase = blockIdx.x * H_QB + wave * 64;
+
+    f16x8 qf[2][H_NCH];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int c = 0; c < H_NCH; ++c)
+            qf[qb][c] = *reinterpret_cast<const f16x8*>(Qh + static_cast<size_t>(qbase + 32 * qb + r) * H_ROW + 16 * c + 8 * h);
+
+    const int ntiles = (nt + H_TT - 1) / H_TT;
+    const int tile0 = blockIdx.y * tiles_per_split;
+    int tile1 = tile0 + tiles_per_split;
+    if (tile1 > ntiles) tile1 = ntiles;
+    f32x4 cl[2] = {{-KNN_BIG, -KNN_BIG, -KNN_BIG, -KNN_BIG}, {-KNN_BIG, -KNN_BIG, -KNN_BIG, -KNN_BIG}};
+
+    HTile st;
+
+    if (tile0 < tile1) {
+        st.load(Th, tile0, tid);
+        st.store(hsm, 0, tid);
+        __syncthreads();
+        f32x16 A0, A1, B0, B1;
+        for (int tix = 0; tix < tile1 - tile0; ++tix) {
+            const int buf = tix & 1;
+            const _Float16* tb = hsm + (buf * H_TT + r) * H_LDS_ROW + 8 * h;
+            const unsigned lb = static_cast<unsigned>(tix) * 64u;          // row ids of this tile: lb + 16*blk + reg
+            // the pad rows of Th cover a whole tile past the last one, so the look-ahead load is safe
+            st.load(Th, tile0 + tix + 1 < ntiles ? tile0 + tix + 1 : tile0 + tix, tid);
+            if (tix == 0) h_block<false>(tb, qf, A0, A1, A0, A1, 0u, keep_mask, cl);
+            else h_block<true>(tb, qf, A0, A1, B0, B1, lb - 16u, keep_mask, cl);                 // B = block 3 of tile-1
+            h_block<true>(tb + 32 * H_LDS_ROW, qf, B0, B1, A0, A1, lb, keep_mask, cl);
+            h_block<true>(tb + 64 * H_LDS_ROW, qf, A0, A1, B0, B1, lb + 16u, keep_mask, cl);
+            st.store(hsm, buf ^ 1, tid);
+            h_block<true>(tb + 96 * H_LDS_ROW, qf, B0, B1, A0, A1, lb + 32u, keep_mask, cl);
+            __syncthreads();
+        }
+        const unsigned lb = static_cast<unsigned>(tile1 - tile0 - 1) * 64u + 48u;
+        h_select(B0, keep_mask, lb, cl[0], 0, 16);
+        h_select(B1, keep_mask, lb, cl[1], 0, 16);
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int q = qbase + 32 * qb + r;
+        if (q < nq) *reinterpret_cast<f32x4*>(cand_val + static_cast<size_t>(q) * slots + (blockIdx.y * 2 + h) * KNN_C) = cl[qb];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // refinement: one wave per query
 // ---------------------------------------------------------------------------------------------
 struct Best2 {
@@ -439,6 +682,19 @@ __device__ __forceinline__ void best2_insert(Best2& b, uint64_t key, float d)
         else { b.k1 = key; b.d1 = d; }
     }
 }
+
+// Candidate-list geometry of one coarse route (how a slot index and the embedded row id map back
+// to a train row, and how wide the refinement window must be).
+struct KnnGeom {
+    const float* cand;        // [nq][slots]
+    int slots;                // splits * 2 * KNN_C
+    int tiles_per_split;
+    int rows_per_tile;        // 64 (f32 route) or 128 (f16 route); ids per tile = rows/2
+    unsigned lid_mask;
+    float eps_coef;           // fp error of the coarse value, times (||q||^2 + max||t||^2)
+    float embed_coef;         // truncation by the embedded id, times (||q||^2 + 2 max||t||^2)
+};
+enum { ROUTE_F32 = 0, ROUTE_F16_HINT = 1, ROUTE_AUTO = 2 };
 
 // position of the r-th (0-based) set bit of m; r < popcount(m)
 __device__ __forceinline__ int nth_set_bit(unsigned long long m, int r)
@@ -499,8 +755,7 @@ template <bool VEC4>
 __global__ __launch_bounds__(256) void knn_l2_refine(
     const float* __restrict__ Q, const float* __restrict__ T, const float* __restrict__ qnorm,
     const unsigned long long* __restrict__ stats, unsigned epoch, unsigned* __restrict__ diag, int nq, int nt,
-    int dim, int k, int slots, const float* __restrict__ cand_val, int tiles_per_split, int rows_per_tile,
-    unsigned lid_mask, float eps_coef, float embed_coef, pm_match* __restrict__ out)
+    int dim, int k, KnnGeom g16, KnnGeom g32, int route, pm_match* __restrict__ out)
 {
     const int lane = threadIdx.x & 63;
     const int q = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -509,7 +764,16 @@ __global__ __launch_bounds__(256) void knn_l2_refine(
     const float na = qnorm[q];
     const unsigned long long s0 = stats[0], s1 = stats[1];
     const float tmax = static_cast<unsigned>(s0 >> 32) == epoch ? __uint_as_float(static_cast<unsigned>(s0)) : 0.f;
-    const bool nonfinite = static_cast<unsigned>(s1 >> 32) == epoch && (s1 & 1ull);
+    const bool flagged = static_cast<unsigned>(s1 >> 32) == epoch;
+    const bool ineligible = flagged && (s1 & 2ull);          // data not integer-valued / too large for f16
+    // which coarse route produced the lists; a wrong integer hint voids them (exact re-scan)
+    const bool use16 = route == ROUTE_F16_HINT || (route == ROUTE_AUTO && !ineligible);
+    const bool nonfinite = (flagged && (s1 & 1ull)) || (route == ROUTE_F16_HINT && ineligible);
+    const KnnGeom g = use16 ? g16 : g32;
+    const int slots = g.slots, tiles_per_split = g.tiles_per_split, rows_per_tile = g.rows_per_tile;
+    const unsigned lid_mask = g.lid_mask;
+    const float eps_coef = g.eps_coef, embed_coef = g.embed_coef;
+    const float* __restrict__ cand_val = g.cand;
     // window half-width: fp error of the coarse value + truncation by the embedded row id
     const float eps = eps_coef * (na + tmax) + embed_coef * (na + 2.f * tmax);
     const float* cv = cand_val + static_cast<size_t>(q) * slots;
@@ -809,7 +1073,8 @@ __global__ __launch_bounds__(256) void knn_l2_exact(const float* __restrict__ Q,
 
 template <int NCH, bool FULL, int TT>
 int launch_mfma(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt, int dim,
-                const float* tnorm, int splits, int tiles_per_split, unsigned keep_mask, float* cval, int slots)
+                const float* tnorm, int splits, int tiles_per_split, unsigned keep_mask, float* cval, int slots,
+                const unsigned long long* stats, unsigned epoch, int only_if_ineligible)
 {
     constexpr int LDT = NCH * 8 + 4;
     const size_t lds = 2 * TT * LDT * sizeof(float);
@@ -822,7 +1087,7 @@ int launch_mfma(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt, i
     dim3 grid((nq + QB - 1) / QB, splits);
     pm::ScopedKernelTime t(ctx, "knn_l2_mfma");
     hipLaunchKernelGGL((knn_l2_mfma<NCH, FULL, TT>), grid, dim3(256), lds, ctx->stream, dq, dt, tnorm, nq, nt, dim,
-                       tiles_per_split, keep_mask, cval, slots);
+                       tiles_per_split, keep_mask, cval, slots, stats, epoch, only_if_ineligible);
     PM_HIP_CHECK(hipGetLastError());
     return PM_OK;
 }
@@ -857,37 +1122,75 @@ extern "C" int pm_bf_knn_l2_f32_dev(pm_ctx* ctx, const float* dq, int nq, const 
 
     const bool fast = !(flags & PM_KNN_FORCE_EXACT) && k <= 2 && (dim % 4) == 0 && dim <= 128 && nt >= 1;
     if (!fast) return run_exact(ctx, dq, nq, dt, nt, dim, k, dout);
+    const int route = (flags & PM_KNN_FORCE_F32) ? ROUTE_F32 : (flags & PM_KNN_HINT_INTEGER) ? ROUTE_F16_HINT : ROUTE_AUTO;
+    const bool want32 = route != ROUTE_F16_HINT, want16 = route != ROUTE_F32;
 
-    // tile height: 64 rows = two workgroups (8 waves) per CU.  (A 128-row tile with one workgroup
-    // per CU measured 172 us against 153 us at C3, so the kernel is instantiated for 64 only.)
-    const int nqb = (nq + QB - 1) / QB;
+    // ---- f32 route geometry: 64-row tiles, 128 queries per workgroup, two workgroups per CU.
+    // (A 128-row tile with one workgroup per CU measured 172 us against 153 us at C3.)
     constexpr int TT = 64;
-    // split the train rows so that the grid fills the chip (TT=64: ~2 workgroups per CU, 128: ~1)
-    const int ntiles = (nt + TT - 1) / TT;
-    int splits = ((TT == 64 ? 2 : 1) * ctx->n_cu + nqb - 1) / nqb;
-    if (splits > ntiles) splits = ntiles;
-    if (splits > 64) splits = 64;
-    if (splits < 1) splits = 1;
-    const int tiles_per_split = (ntiles + splits - 1) / splits;
-    splits = (ntiles + tiles_per_split - 1) / tiles_per_split;
-    const int slots = splits * 2 * KNN_C;
-    // row id inside a lane's stream: tile_in_split*(TT/2) + block*16 + reg, in the low mantissa bits
-    int lid_bits = 5;
-    while ((1 << lid_bits) < tiles_per_split * (TT / 2)) ++lid_bits;
-    if (lid_bits > 16) return run_exact(ctx, dq, nq, dt, nt, dim, k, dout);     // > 2048 tiles per split
-    const unsigned lid_mask = (1u << lid_bits) - 1u;
+    KnnGeom g32{}, g16{};
+    int splits32 = 1, splits16 = 1, lid_bits32 = 5, lid_bits16 = 6;
+    {
+        const int nqb = (nq + QB - 1) / QB;
+        const int ntiles = (nt + TT - 1) / TT;
+        int splits = (2 * ctx->n_cu + nqb - 1) / nqb;
+        if (splits > ntiles) splits = ntiles;
+        if (splits > 64) splits = 64;
+        if (splits < 1) splits = 1;
+        g32.tiles_per_split = (ntiles + splits - 1) / splits;
+        splits32 = (ntiles + g32.tiles_per_split - 1) / g32.tiles_per_split;
+        g32.slots = splits32 * 2 * KNN_C;
+        g32.rows_per_tile = TT;
+        // row id inside a lane's stream: tile_in_split*(TT/2) + block*16 + reg, in the low mantissa bits
+        while ((1 << lid_bits32) < g32.tiles_per_split * (TT / 2)) ++lid_bits32;
+        g32.lid_mask = (1u << lid_bits32) - 1u;
+        // |coarse - canonical| <= (6*dim + 32) * 2^-24 * (||q||^2 + ||t||^2), plus the id truncation
+        // 2^(bits-23) * (||q||^2 + 2||t||^2); see docs/SPEC.md S1b
+        g32.eps_coef = static_cast<float>((6.0 * dim + 32.0) * 5.9604644775390625e-8 * 1.001);
+        g32.embed_coef = static_cast<float>(static_cast<double>(1u << lid_bits32) * 1.1920928955078125e-7 * 1.01);
+    }
+    // ---- f16 route geometry: 128-row tiles, 256 queries per workgroup (4 waves x 64)
+    const int nq_pad = (nq + H_QB - 1) / H_QB * H_QB, nt_pad = (nt + H_TT - 1) / H_TT * H_TT;
+    {
+        const int nqb = nq_pad / H_QB;
+        const int ntiles = nt_pad / H_TT;
+        int splits = (2 * ctx->n_cu + nqb - 1) / nqb;
+        if (splits > ntiles) splits = ntiles;
+        if (splits > 64) splits = 64;
+        if (splits < 1) splits = 1;
+        g16.tiles_per_split = (ntiles + splits - 1) / splits;
+        splits16 = (ntiles + g16.tiles_per_split - 1) / g16.tiles_per_split;
+        g16.slots = splits16 * 2 * KNN_C;
+        g16.rows_per_tile = H_TT;
+        while ((1 << lid_bits16) < g16.tiles_per_split * (H_TT / 2)) ++lid_bits16;
+        g16.lid_mask = (1u << lid_bits16) - 1u;
+        g16.eps_coef = 0.f;           // integer data: the f16 products and f32 sums are exact
+        g16.embed_coef = static_cast<float>(static_cast<double>(1u << lid_bits16) * 1.1920928955078125e-7 * 1.01);
+    }
+    if ((want32 && lid_bits32 > 16) || (want16 && lid_bits16 > 16))
+        return run_exact(ctx, dq, nq, dt, nt, dim, k, dout);     // > 64k rows per lane stream
 
-    // scratch: norms, stats, candidate lists.  The arena is carved per call; callers that
+    // scratch: norms, f16 copies, candidate lists.  The arena is carved per call; callers that
     // interleave calls on one context are serialised by the stream.
+    const size_t c32 = want32 ? sizeof(float) * static_cast<size_t>(nq) * g32.slots : 0;
+    const size_t c16 = want16 ? sizeof(float) * static_cast<size_t>(nq) * g16.slots : 0;
+    const size_t qh = want16 ? sizeof(_Float16) * static_cast<size_t>(nq_pad) * H_ROW : 0;
+    const size_t th = want16 ? sizeof(_Float16) * static_cast<size_t>(nt_pad) * H_ROW : 0;
     const size_t need = pm::align_up(sizeof(float) * nq, 256) + pm::align_up(sizeof(float) * nt, 256) +
-                        pm::align_up(sizeof(float) * static_cast<size_t>(nq) * slots, 256) + 1024;
+                        pm::align_up(c32, 256) + pm::align_up(c16, 256) + pm::align_up(qh, 256) + pm::align_up(th, 256) + 2048;
     int rc = pm::arena_reserve(ctx, need);
     if (rc != PM_OK) return rc;
     pm::arena_reset(ctx);
     float* qnorm = static_cast<float*>(pm::arena_take(ctx, sizeof(float) * nq));
     float* tnorm = static_cast<float*>(pm::arena_take(ctx, sizeof(float) * nt));
-    float* cval = static_cast<float*>(pm::arena_take(ctx, sizeof(float) * static_cast<size_t>(nq) * slots));
-    PM_REQUIRE(qnorm && tnorm && cval, PM_E_NOMEM, "scratch arena too small");
+    float* cval32 = want32 ? static_cast<float*>(pm::arena_take(ctx, c32)) : nullptr;
+    float* cval16 = want16 ? static_cast<float*>(pm::arena_take(ctx, c16)) : nullptr;
+    _Float16* Qh = want16 ? static_cast<_Float16*>(pm::arena_take(ctx, qh)) : nullptr;
+    _Float16* Th = want16 ? static_cast<_Float16*>(pm::arena_take(ctx, th)) : nullptr;
+    PM_REQUIRE(qnorm && tnorm && (!want32 || cval32) && (!want16 || (cval16 && Qh && Th)), PM_E_NOMEM,
+               "scratch arena too small");
+    g32.cand = cval32;
+    g16.cand = cval16;
 
     unsigned long long* stats = ctx->knn_stats;          // persistent, epoch-tagged: never cleared
     if (++ctx->knn_epoch == 0u) {              // 2^32 calls: restart the epoch tags
@@ -902,30 +1205,46 @@ extern "C" int pm_bf_knn_l2_f32_dev(pm_ctx* ctx, const float* dq, int nq, const 
     }
     {
         pm::ScopedKernelTime t(ctx, "knn_l2_prep");
-        hipLaunchKernelGGL(knn_l2_prep, dim3((nq + 63) / 64 + (nt + 63) / 64), dim3(256), 0, ctx->stream, dq, nq, dt,
-                           nt, dim, qnorm, tnorm, stats, epoch);
+        if (want16)
+            hipLaunchKernelGGL(knn_l2_prep16, dim3(nq_pad / 64 + nt_pad / 64), dim3(256), 0, ctx->stream, dq, nq, nq_pad,
+                               dt, nt, nt_pad, dim, qnorm, tnorm, Qh, Th, stats, epoch);
+        else
+            hipLaunchKernelGGL(knn_l2_prep, dim3((nq + 63) / 64 + (nt + 63) / 64), dim3(256), 0, ctx->stream, dq, nq, dt,
+                               nt, dim, qnorm, tnorm, stats, epoch);
         PM_HIP_CHECK(hipGetLastError());
     }
-#define PM_LAUNCH_MFMA(NCH_, FULL_) \
-    launch_mfma<NCH_, FULL_, TT>(ctx, dq, nq, dt, nt, dim, tnorm, splits, tiles_per_split, ~lid_mask, cval, slots)
-    if (dim == 128) rc = PM_LAUNCH_MFMA(16, true);
-    else if (dim == 64) rc = PM_LAUNCH_MFMA(8, true);
-    else if (dim == 32) rc = PM_LAUNCH_MFMA(4, true);
-    else if (dim < 32) rc = PM_LAUNCH_MFMA(4, false);
-    else if (dim < 64) rc = PM_LAUNCH_MFMA(8, false);
-    else rc = PM_LAUNCH_MFMA(16, false);
+    if (want16) {
+        const size_t lds = sizeof(_Float16) * 2 * H_TT * H_LDS_ROW;
+        static bool attr_done = false;
+        if (!attr_done) {
+            PM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_l2_mfma_f16),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+            attr_done = true;
+        }
+        pm::ScopedKernelTime t(ctx, "knn_l2_mfma_f16");
+        hipLaunchKernelGGL(knn_l2_mfma_f16, dim3(nq_pad / H_QB, splits16), dim3(256), lds, ctx->stream, Qh, Th, nq, nt,
+                           g16.tiles_per_split, ~g16.lid_mask, cval16, g16.slots, stats, epoch,
+                           route == ROUTE_AUTO ? 1 : 0);
+        PM_HIP_CHECK(hipGetLastError());
+    }
+    if (want32) {
+        const int only = route == ROUTE_AUTO ? 1 : 0;
+#define PM_LAUNCH_MFMA(NCH_, FULL_)                                                                              \
+    launch_mfma<NCH_, FULL_, TT>(ctx, dq, nq, dt, nt, dim, tnorm, splits32, g32.tiles_per_split, ~g32.lid_mask, \
+                                 cval32, g32.slots, stats, epoch, only)
+        if (dim == 128) rc = PM_LAUNCH_MFMA(16, true);
+        else if (dim == 64) rc = PM_LAUNCH_MFMA(8, true);
+        else if (dim == 32) rc = PM_LAUNCH_MFMA(4, true);
+        else if (dim < 32) rc = PM_LAUNCH_MFMA(4, false);
+        else if (dim < 64) rc = PM_LAUNCH_MFMA(8, false);
+        else rc = PM_LAUNCH_MFMA(16, false);
 #undef PM_LAUNCH_MFMA
-    if (rc != PM_OK) return rc;
-
-    // |coarse - canonical| <= (6*dim + 32) * 2^-24 * (||q||^2 + ||t||^2) + 2^(bits-23) * (||q||^2 + 2||t||^2);
-    // see docs/SPEC.md S1b
-    const float eps_coef = static_cast<float>((6.0 * dim + 32.0) * 5.9604644775390625e-8 * 1.001);
-    const float embed_coef = static_cast<float>(static_cast<double>(1u << lid_bits) * 1.1920928955078125e-7 * 1.01);
+        if (rc != PM_OK) return rc;
+    }
     {
         pm::ScopedKernelTime t(ctx, "knn_l2_refine");
         hipLaunchKernelGGL(knn_l2_refine<true>, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, dq, dt, qnorm, stats,
-                           epoch, diag, nq, nt, dim, k, slots, cval, tiles_per_split, TT, lid_mask, eps_coef,
-                           embed_coef, dout);
+                           epoch, diag, nq, nt, dim, k, g16, g32, route, dout);
         PM_HIP_CHECK(hipGetLastError());
     }
     return PM_OK;

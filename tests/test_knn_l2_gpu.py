@@ -6,7 +6,7 @@ import pytest
 
 import points_matching_amd as pm
 from points_matching_amd import synth
-from points_matching_amd.api import PM_KNN_FORCE_EXACT
+from points_matching_amd.api import PM_KNN_FORCE_EXACT, PM_KNN_FORCE_F32, PM_KNN_HINT_INTEGER
 from util import assert_matches_equal
 
 pytestmark = pytest.mark.gpu
@@ -17,7 +17,10 @@ pytestmark = pytest.mark.gpu
 def test_knn_small_both_paths(ctx, oracle, gen, k):
     q, t, truth = (synth.sift_like if gen == "sift" else synth.surf_like)(256, 256, 128, seed=11)
     want = oracle.bf_knn_l2(q, t, k)
-    assert_matches_equal(ctx.bf_knn_l2(q, t, k), want, "fast")
+    assert_matches_equal(ctx.bf_knn_l2(q, t, k), want, "auto route")
+    assert_matches_equal(ctx.bf_knn_l2(q, t, k, PM_KNN_FORCE_F32), want, "f32-MFMA route")
+    # integer hint: the f16 route for sift data; for surf data the hint is WRONG and must only cost time
+    assert_matches_equal(ctx.bf_knn_l2(q, t, k, PM_KNN_HINT_INTEGER), want, "f16 route / wrong hint")
     assert_matches_equal(ctx.bf_knn_l2(q, t, k, PM_KNN_FORCE_EXACT), want, "exact")
     planted = truth >= 0
     assert (want["trainIdx"][planted, 0] == truth[planted]).all()
@@ -31,6 +34,11 @@ def test_knn_ragged_shapes(ctx, oracle, nq, nt, dim):
         want = oracle.bf_knn_l2(q, t, k)
         assert_matches_equal(ctx.bf_knn_l2(q, t, k), want, "fast %s" % ((nq, nt, dim, k),))
         assert_matches_equal(ctx.bf_knn_l2(q, t, k, PM_KNN_FORCE_EXACT), want, "exact")
+    qi, ti, _ = synth.sift_like(nq, nt, dim, seed=nq * 1000 + nt + 1)       # integer data: f16 route
+    for k in (1, 2):
+        want = oracle.bf_knn_l2(qi, ti, k)
+        for flags in (0, PM_KNN_HINT_INTEGER, PM_KNN_FORCE_F32):
+            assert_matches_equal(ctx.bf_knn_l2(qi, ti, k, flags), want, "int %s" % ((nq, nt, dim, k, flags),))
 
 
 @pytest.mark.parametrize("nq,nt,dim,k", [(40, 90, 7, 2), (40, 90, 200, 1), (70, 300, 130, 3),
@@ -53,8 +61,8 @@ def test_knn_duplicate_rows_lowest_index_wins(ctx, oracle):
     want = oracle.bf_knn_l2(q, t, 2)
     assert want["trainIdx"][5, 0] == 10 and want["trainIdx"][5, 1] == 77
     assert want["trainIdx"][6, 0] == 20 and want["trainIdx"][6, 1] == 128
-    assert_matches_equal(ctx.bf_knn_l2(q, t, 2), want, "dups fast")
-    assert_matches_equal(ctx.bf_knn_l2(q, t, 2, PM_KNN_FORCE_EXACT), want, "dups exact")
+    for flags in (0, PM_KNN_HINT_INTEGER, PM_KNN_FORCE_F32, PM_KNN_FORCE_EXACT):
+        assert_matches_equal(ctx.bf_knn_l2(q, t, 2, flags), want, "dups flags=%d" % flags)
 
 
 def test_knn_near_ties_general_floats(ctx, oracle):
@@ -122,6 +130,8 @@ def test_knn_c3_8k_full_size(ctx, oracle):
     got = ctx.bf_knn_l2(q, t, 2)
     want = oracle.bf_knn_l2(q, t, 2, nthreads=8)
     assert_matches_equal(got, want, "C3")
+    assert_matches_equal(ctx.bf_knn_l2(q, t, 2, PM_KNN_FORCE_F32), want, "C3 f32 route")
+    assert_matches_equal(ctx.bf_knn_l2(q, t, 2, PM_KNN_HINT_INTEGER), want, "C3 f16 route")
     # properties: rows sorted, indices in range and distinct, planted pairs found, and the
     # reported distance is the canonical distance of the reported pair
     assert (got["distance"][:, 0] <= got["distance"][:, 1]).all()
@@ -136,3 +146,19 @@ def test_knn_c3_8k_full_size(ctx, oracle):
     perm = np.random.default_rng(1).permutation(8192)
     got_p = ctx.bf_knn_l2(q[:512], t[perm], 1)
     assert (perm[got_p["trainIdx"][:, 0]] == got["trainIdx"][:512, 0]).mean() > 0.999
+
+
+def test_knn_integer_eligibility_edge(ctx, oracle):
+    """|x| <= 361 is f16-exact territory; one larger value must push the call to the f32 route
+    (auto) or the exact re-scan (wrong hint) with identical results."""
+    rng = np.random.default_rng(77)
+    q = rng.integers(-361, 362, (200, 128)).astype(np.float32)
+    t = rng.integers(-361, 362, (300, 128)).astype(np.float32)
+    want = oracle.bf_knn_l2(q, t, 2)
+    for flags in (0, PM_KNN_HINT_INTEGER, PM_KNN_FORCE_F32):
+        assert_matches_equal(ctx.bf_knn_l2(q, t, 2, flags), want, "edge flags=%d" % flags)
+    t[17, 5] = 400.0
+    q[3, 9] = 0.5
+    want = oracle.bf_knn_l2(q, t, 2)
+    for flags in (0, PM_KNN_HINT_INTEGER, PM_KNN_FORCE_F32):
+        assert_matches_equal(ctx.bf_knn_l2(q, t, 2, flags), want, "beyond flags=%d" % flags)
