@@ -185,6 +185,14 @@ __device__ __forceinline__ float embed_lid(float w, unsigned keep_mask, unsigned
     return r;
 }
 
+// same with the row id in an SGPR (it is wave-uniform on the f16 route): saves the v_mov
+__device__ __forceinline__ float embed_lid_s(float w, unsigned keep_mask, unsigned lid_uniform)
+{
+    float r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(keep_mask), "v"(w), "s"(lid_uniform));
+    return r;
+}
+
 // The builtin forms make hipcc put a canonicalising v_max_f32 x,x in front of every operand
 // (IEEE mode: the result of fmax/fmed3 must be quiet), three extra VALU ops per candidate.
 // The operands here are finite by construction (non-finite inputs divert to the re-scan), so the
@@ -578,7 +586,7 @@ __device__ __forceinline__ void h_select(const f32x16& acc, unsigned keep_mask, 
                                          int v1)
 {
 #pragma unroll
-    for (int v = v0; v < v1; ++v) top4_insert(cl, embed_lid(acc[v], keep_mask, lidbase + static_cast<unsigned>(v)));
+    for (int v = v0; v < v1; ++v) top4_insert(cl, embed_lid_s(acc[v], keep_mask, lidbase + static_cast<unsigned>(v)));
 }
 
 // one 32-row block of the tile: 9 k-chunks x 2 query blocks = 18 MFMAs, selecting the previous
@@ -589,11 +597,15 @@ __device__ __forceinline__ void h_block(const _Float16* __restrict__ tb, const f
                                         unsigned keep_mask, f32x4 (&cl)[2])
 {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    f16x8 xn = *reinterpret_cast<const f16x8*>(tb);
+    // A fragments run three chunks (= 6 MFMAs, ~190 cycles) ahead of their use: one chunk is only
+    // 64 pipe cycles, less than an LDS round trip
+    f16x8 ring[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ring[c] = *reinterpret_cast<const f16x8*>(tb + 16 * c);
 #pragma unroll
     for (int c = 0; c < H_NCH; ++c) {
-        const f16x8 x = xn;
-        if (c + 1 < H_NCH) xn = *reinterpret_cast<const f16x8*>(tb + 16 * (c + 1));
+        const f16x8 x = ring[c % 3];
+        if (c + 3 < H_NCH) ring[c % 3] = *reinterpret_cast<const f16x8*>(tb + 16 * (c + 3));
         a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, qf[0][c], c == 0 ? zero : a0, 0, 0, 0);
         a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, qf[1][c], c == 0 ? zero : a1, 0, 0, 0);
         if (EPI && c < 8) {                       // 32 values over the first 8 chunks: 2 per query column
@@ -628,6 +640,17 @@ __global__ __launch_bounds__(256, 2) void knn_l2_mfma_f16(const _Float16* __rest
 #pragma unroll
         for (int c = 0; c < H_NCH; ++c)
             qf[qb][c] = *reinterpret_cast<const f16x8*>(Qh + static_cast<size_t>(qbase + 32 * qb + r) * H_ROW + 16 * c + 8 * h);
+    // make the fragments opaque: hipcc otherwise treats the loads as rematerialisable and re-reads
+    // half of them from global memory inside the tile loop (18 loads + waits per tile)
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int c = 0; c < H_NCH; ++c) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 t = __builtin_bit_cast(u32x4, qf[qb][c]);
+            asm volatile("" : "+v"(t));
+            qf[qb][c] = __builtin_bit_cast(f16x8, t);
+        }
 
     const int ntiles = (nt + H_TT - 1) / H_TT;
     const int tile0 = blockIdx.y * tiles_per_split;
