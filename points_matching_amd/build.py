@@ -16,7 +16,9 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libpm_hip.so")
-SOURCES = ["pm_capi.cpp", "knn_l2.hip", "knn_hamming.hip", "ransac.hip", "filter_gather.hip"]
+SOURCES = ["pm_capi.cpp", "knn_l2.hip", "knn_coarse.hip", "knn_hamming.hip", "ransac.hip", "filter_gather.hip"]
+# per-file extra flags: the coarse kernels only nominate candidates (no result bit depends on them)
+EXTRA = {"knn_coarse.hip": ["-ffinite-math-only"]}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function",
@@ -44,7 +46,7 @@ def build(force=False, verbose=False, extra_flags=()):
         o = os.path.join(OBJ, src.rsplit(".", 1)[0] + ".o")
         objs.append(o)
         if force or _newer(s, o) or any(_newer(d, o) for d in deps):
-            cmd = [HIPCC] + FLAGS + list(extra_flags) + (["-x", "hip"] if src.endswith(".hip") else []) + \
+            cmd = [HIPCC] + FLAGS + EXTRA.get(src, []) + list(extra_flags) + (["-x", "hip"] if src.endswith(".hip") else []) + \
                   ["-c", s, "-o", o]
             jobs.append(cmd)
 

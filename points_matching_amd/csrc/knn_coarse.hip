@@ -1,0 +1,477 @@
+// knn_coarse.hip — the two MFMA coarse passes of the L2 matcher (see knn_l2.hip for the overall
+// scheme and docs/SPEC.md S1b for the error bounds).  Replaces, together with knn_l2.hip,
+// `matcher.match(imageDesc1, imageDesc2, matchePoints, Mat())` (main.cpp:46).
+//
+// Built with -ffinite-math-only (see knn_shared.hpp).  Nothing in this file decides a result bit:
+// the coarse values only nominate candidate rows for the canonical refinement.
+#include "knn_shared.hpp"
+
+namespace pm_knn {
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// coarse pass on the matrix cores
+//
+// Per (query, train row) the MFMA chain accumulates w = q.t - ||t||^2/2 = -(d2a - ||q||^2)/2 (the
+// seed -||t||^2/2 is one more k-step of the chain): the LARGEST w are the nearest rows.  The row's position in this lane's stream
+// (lid = tile_in_split*32 + block*16 + reg) is written into the low `bits` mantissa bits of w, so
+// a candidate is ONE float and keeping the 4 largest is branch-free:
+//     n0 = max(x,w0); n1 = med3(x,w0,w1); n2 = med3(x,w1,w2); n3 = med3(x,w2,w3)
+// (5 VALU per pair incl. the bit insert).  The truncation error 2^(bits-23)*|w| is part of the
+// refinement's window (SPEC S1b).  Two accumulator sets: the epilogue of tile t-1 is issued
+// between the MFMAs of tile t, so the matrix pipe does not wait for the selection.
+// ---------------------------------------------------------------------------------------------
+// (keep & w) | (~keep & id): the id lands in the low mantissa bits (hipcc emits v_bfi / v_and_or)
+__device__ __forceinline__ float embed_lid(float w, unsigned keep_mask, unsigned lid)
+{
+    return __uint_as_float((__float_as_uint(w) & keep_mask) | (lid & ~keep_mask));
+}
+
+// This translation unit is built with -ffinite-math-only: fmaxf / fmed3 then need no canonicalising
+// v_max in front of every operand (the operands ARE finite here: non-finite inputs divert to the
+// exact re-scan), and because these are compiler-visible instructions hipcc's hazard recogniser
+// keeps the required distance between an MFMA and the first VALU read of its result.  (An
+// earlier version used inline-asm v_max3/v_med3 directly on the accumulators: hipcc pads nothing
+// inside or in front of asm, and the f16 route then read accumulators one k-chunk early.)
+__device__ __forceinline__ void top4_insert(f32x4& c, float x)
+{
+    const float n0 = fmaxf(x, c[0]);
+    const float n1 = __builtin_amdgcn_fmed3f(x, c[0], c[1]);
+    const float n2 = __builtin_amdgcn_fmed3f(x, c[1], c[2]);
+    const float n3 = __builtin_amdgcn_fmed3f(x, c[2], c[3]);
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+// GROUPED selection.  Registers 4g..4g+3 of an accumulator are four CONSECUTIVE train rows
+// (8g + 4*(lane>>5) + {0,1,2,3} of the 32-row block).  Only the group's largest w competes for the
+// list (2 VALU per 4 values: v_max3 + v_max), tagged with the GROUP id; the refinement
+// re-evaluates all four rows of a candidate group.  That is sound: a row inside the window has a
+// group maximum inside the window, and the k largest group maxima are attained by k distinct rows.
+// VALU cost per descriptor pair: (2 + 1 + 4) / 4 = 1.75 instead of 5 — the selection, not the
+// matrix pipe, is what bounds the f16 route.
+__device__ __forceinline__ float group_max(const f32x16& acc, int g)
+{
+    return fmaxf(fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), acc[4 * g + 2]), acc[4 * g + 3]);
+}
+
+// NCH = padded dim / 8; FULL = (dim == 8*NCH), which drops the column guards; TT = train rows
+// per LDS tile (64: two workgroups per CU, 128: one workgroup per CU with twice the MFMA work
+// between barriers).  grid = (ceil(nq/QB), splits).  Dynamic LDS: 2 tiles of TT x (8*NCH + 4)
+// floats (row stride padded by one 16-B slot: conflict-free ds_read_b128 for the 16 rows of a lane
+// group) + 2 x TT seeds (-||t||^2/2, or -KNN_BIG/2 past the last row).
+template <int NCH, bool FULL, int TT>
+struct KnnTile {
+    static constexpr int DP = NCH * 8;
+    static constexpr int LDT = DP + 4;
+    static constexpr int F4_PER_ROW = DP / 4;
+    static constexpr int NSTG = TT * F4_PER_ROW / 256;
+    static_assert(TT * F4_PER_ROW % 256 == 0, "tile must split evenly over the workgroup");
+
+    f32x4 stg[NSTG];
+    float stg_n;
+
+    // global -> registers (unconditional loads: clamped addresses, zero-select afterwards)
+    __device__ __forceinline__ void load(const float* __restrict__ T, const float* __restrict__ tnorm, int tile,
+                                         int nt, int dim, int tid)
+    {
+#pragma unroll
+        for (int i = 0; i < NSTG; ++i) {
+            const int f = tid + 256 * i;
+            const int row = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
+            int g = tile * TT + row;
+            g = g < nt ? g : nt - 1;
+            int col = 4 * c4;
+            if (!FULL) col = col < dim ? col : dim - 4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(T + static_cast<size_t>(g) * dim + col);
+            if (!FULL && 4 * c4 >= dim) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            stg[i] = v;
+        }
+        const int gn = tile * TT + (tid & (TT - 1));
+        const float nrm = tnorm[gn < nt ? gn : nt - 1];
+        stg_n = gn < nt ? -0.5f * nrm : -0.5f * KNN_BIG;
+    }
+    // registers -> LDS buffer
+    // the row seed -||t||^2/2 travels in the row's 16-byte pad slot: (seed, 0, 0, 0)
+    __device__ __forceinline__ void store(float* __restrict__ Ts, int buf, int tid) const
+    {
+#pragma unroll
+        for (int i = 0; i < NSTG; ++i) {
+            const int f = tid + 256 * i;
+            const int row = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
+            *reinterpret_cast<f32x4*>(Ts + (buf * TT + row) * LDT + 4 * c4) = stg[i];
+        }
+        if (tid < TT) *reinterpret_cast<f32x4*>(Ts + (buf * TT + tid) * LDT + DP) = f32x4{stg_n, 0.f, 0.f, 0.f};
+    }
+};
+
+// One tile of the sweep.  Everything that is not an MFMA is issued INSIDE the chain, in the shadow
+// of a 64-cycle MFMA: the global loads of the next tile after chunk 0, the selection of the
+// previous tile's accumulators p[] spread over all chunks, and the LDS writes of the next tile
+// after the last-but-one chunk.  The row seed -||t||^2/2 enters through the matrix pipe as well:
+// one extra k-step per block multiplies the pad column (seed, 0) of the A tile by (1, 0), starting
+// from the inline constant C = 0, so no accumulator is initialised and the selection needs no
+// add.  The next tile is always staged (clamped addresses; past the end the data is unused),
+// which keeps the chain free of branches.
+// C[i][j] of lane (j = lane&31), register reg is train row i = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+template <int NCH, bool FULL, int NB, bool EPI>
+__device__ __forceinline__ void knn_tile_compute(float* __restrict__ Ts, int buf, int r, int h,
+                                                 const f32x4 (&qf)[NCH], f32x16 (&a)[NB], const f32x16 (&p)[NB],
+                                                 unsigned pbase, unsigned keep_mask, f32x4& cl,
+                                                 KnnTile<NCH, FULL, NB * 32>& st, const float* __restrict__ T,
+                                                 const float* __restrict__ tnorm, int next_tile, int nt, int dim,
+                                                 int tid)
+{
+    constexpr int DP = NCH * 8;
+    constexpr int LDT = DP + 4;
+    constexpr int TT = NB * 32;
+    static_assert(NCH >= 4, "the in-chain schedule needs at least 4 chunks");
+    const float* tb = Ts + buf * TT * LDT + r * LDT + 4 * h;
+    const float one_or_zero = h == 0 ? 1.f : 0.f;          // B side of the seed step: k = h
+    float sda[NB];                                          // A side: pad[h] = (seed, 0)[h]
+    f32x4 xn[NB];                                           // A fragments, one chunk ahead of their MFMAs
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+        sda[blk] = Ts[buf * TT * LDT + (32 * blk + r) * LDT + DP + h];
+        xn[blk] = *reinterpret_cast<const f32x4*>(tb + 32 * blk * LDT);
+    }
+    {
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk)
+            a[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(sda[blk], one_or_zero, zero, 0, 0, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        f32x4 x[NB];
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) x[blk] = xn[blk];
+#ifndef PM_ABL_NOLDSREAD
+        if (c + 1 < NCH) {
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk)
+                xn[blk] = *reinterpret_cast<const f32x4*>(tb + 32 * blk * LDT + 8 * (c + 1));
+        }
+#endif
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk)
+                a[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[blk][t], qf[c][t], a[blk], 0, 0, 0);
+#ifndef PM_ABL_NOSTAGE
+        if (c == 0) st.load(T, tnorm, next_tile, nt, dim, tid);                       // global -> registers
+        if (c == NCH - 2) st.store(Ts, buf ^ 1, tid);                                 // registers -> LDS
+#endif
+#ifdef PM_ABL_NOEPI
+        if (false) {
+#else
+        if (EPI) {
+#endif
+            // row groups of the previous tile, spread over chunks 1..NCH-1 (chunk 0 is left alone so
+            // that a full round of this tile's MFMAs separates the previous tile's last MFMA from
+            // the first read of its accumulators)
+            constexpr int NG = 4 * NB;
+#pragma unroll
+            for (int g = (c == 0 ? 0 : (c - 1) * NG / (NCH - 1)); g < (c == 0 ? 0 : c * NG / (NCH - 1)); ++g)      // block g>>2, group g&3
+                top4_insert(cl, embed_lid(group_max(p[g >> 2], g & 3), keep_mask, pbase + static_cast<unsigned>(g)));
+            // pin the selection to this chunk: without a use here hipcc sinks all of it below the
+            // MFMA chain (in front of the barrier), where nothing hides it.
+            asm volatile("" : "+v"(cl[0]), "+v"(cl[1]), "+v"(cl[2]), "+v"(cl[3]));
+        }
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void knn_select_all(const f32x16 (&p)[NB], unsigned pbase, unsigned keep_mask, f32x4& cl)
+{
+#pragma unroll
+    for (int g = 0; g < 4 * NB; ++g)
+        top4_insert(cl, embed_lid(group_max(p[g >> 2], g & 3), keep_mask, pbase + static_cast<unsigned>(g)));
+}
+
+#ifdef PM_ABL_NOBARRIER
+#define PM_TILE_BARRIER() asm volatile("" ::: "memory")
+#else
+#define PM_TILE_BARRIER() __syncthreads()
+#endif
+
+template <int NCH, bool FULL, int TT>
+__global__ __launch_bounds__(256, (TT == 64 ? 2 : 1)) void knn_l2_mfma(
+    const float* __restrict__ Q, const float* __restrict__ T, const float* __restrict__ tnorm, int nq,
+    int nt, int dim, int tiles_per_split, unsigned keep_mask, float* __restrict__ cand_val, int slots,
+    const unsigned long long* __restrict__ stats, unsigned epoch, int only_if_ineligible)
+{
+    if (only_if_ineligible) {                  // auto mode: the f16 route handles eligible data
+        const unsigned long long s1 = stats[1];
+        if (!(static_cast<unsigned>(s1 >> 32) == epoch && (s1 & 2ull))) return;
+    }
+    using Tile = KnnTile<NCH, FULL, TT>;
+    constexpr int LDT = Tile::LDT;
+    constexpr int NB = TT / 32;
+    constexpr unsigned IDS = 4 * NB;           // row-group ids a lane sees per tile
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ts = smem;                          // [2][TT][LDT], seed in each row's pad slot
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int qrow = blockIdx.x * QB + wave * 32 + r;
+    const int qld = qrow < nq ? qrow : nq - 1;
+
+    // B operand: this lane's query row, k = 8c + 4h + {0..3} for chunk c (the k permutation is
+    // shared with the A operand, and a dot product does not care about k order).
+    f32x4 qf[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int k0 = 8 * c + 4 * h;
+        int col = k0;
+        if (!FULL) col = col < dim ? col : dim - 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(Q + static_cast<size_t>(qld) * dim + col);
+        if (!FULL && k0 >= dim) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        qf[c] = v;
+    }
+
+    const int ntiles = (nt + TT - 1) / TT;
+    const int tile0 = blockIdx.y * tiles_per_split;
+    int tile1 = tile0 + tiles_per_split;
+    if (tile1 > ntiles) tile1 = ntiles;
+
+    f32x4 cl = {-KNN_BIG, -KNN_BIG, -KNN_BIG, -KNN_BIG};
+    if (tile0 < tile1) {                       // block-uniform
+        Tile st;
+        st.load(T, tnorm, tile0, nt, dim, tid);
+        st.store(Ts, 0, tid);
+        __syncthreads();
+
+        // every accumulator has a compile-time name: tiles alternate A, B, A, ...  (tix = tile - tile0)
+        f32x16 accA[NB], accB[NB];
+        int tix = 0;
+        const int ntl = tile1 - tile0;
+        knn_tile_compute<NCH, FULL, NB, false>(Ts, 0, r, h, qf, accA, accA, 0u, keep_mask, cl, st, T, tnorm,
+                                               tile0 + 1, nt, dim, tid);
+        PM_TILE_BARRIER();
+        ++tix;
+        for (;;) {
+            if (tix >= ntl) { knn_select_all<NB>(accA, static_cast<unsigned>(tix - 1) * IDS, keep_mask, cl); break; }
+            // tile -> B while selecting A (tile-1)
+            knn_tile_compute<NCH, FULL, NB, true>(Ts, tix & 1, r, h, qf, accB, accA, static_cast<unsigned>(tix - 1) * IDS,
+                                                  keep_mask, cl, st, T, tnorm, tile0 + tix + 1, nt, dim, tid);
+            PM_TILE_BARRIER();
+            ++tix;
+            if (tix >= ntl) { knn_select_all<NB>(accB, static_cast<unsigned>(tix - 1) * IDS, keep_mask, cl); break; }
+            // tile -> A while selecting B (tile-1)
+            knn_tile_compute<NCH, FULL, NB, true>(Ts, tix & 1, r, h, qf, accA, accB, static_cast<unsigned>(tix - 1) * IDS,
+                                                  keep_mask, cl, st, T, tnorm, tile0 + tix + 1, nt, dim, tid);
+            PM_TILE_BARRIER();
+            ++tix;
+        }
+    }
+
+    if (qrow < nq) {
+        const size_t o = static_cast<size_t>(qrow) * slots + (blockIdx.y * 2 + h) * KNN_C;
+        *reinterpret_cast<f32x4*>(cand_val + o) = cl;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// f16 route: integer-valued descriptors (what OpenCV's SIFT emits: 0..255 stored as float).
+// knn_l2_prep16 (knn_l2.hip) writes the padded f16 copies and verifies eligibility; see there.
+//
+// At this matrix rate the selection is as expensive as the MFMAs, so the kernel is organised
+// around it: a wave owns 64 queries (two B blocks: every A fragment read from LDS feeds two
+// MFMAs), walks the 128-row tile one 32-row block at a time and selects block b-1 between the
+// MFMAs of block b, with two alternating accumulator sets.
+// ---------------------------------------------------------------------------------------------
+// a tile = 128 rows x 288 B = 2304 x 16 B: nine 16-byte pieces per thread, staged through registers
+struct HTile {
+    static constexpr int PIECES = H_TT * (H_ROW / 8) / 256;
+    static_assert(H_TT * (H_ROW / 8) % 256 == 0, "tile must split evenly over the workgroup");
+    uint4 stg[PIECES];
+    __device__ __forceinline__ void load(const _Float16* __restrict__ Th, int tile, int tid)
+    {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int f = tid + 256 * i;
+            const int row = f / (H_ROW / 8), c8 = f % (H_ROW / 8);
+            stg[i] = *reinterpret_cast<const uint4*>(Th + static_cast<size_t>(tile * H_TT + row) * H_ROW + 8 * c8);
+        }
+    }
+    __device__ __forceinline__ void store(_Float16* __restrict__ hsm, int buf, int tid) const
+    {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int f = tid + 256 * i;
+            const int row = f / (H_ROW / 8), c8 = f % (H_ROW / 8);
+            *reinterpret_cast<uint4*>(hsm + (buf * H_TT + row) * H_LDS_ROW + 8 * c8) = stg[i];
+        }
+    }
+};
+
+// keep the 4 largest row groups of this lane's stream for one of its two query columns
+__device__ __forceinline__ void h_select(const f32x16& acc, unsigned keep_mask, unsigned gidbase, f32x4& cl, int g0,
+                                         int g1)
+{
+#pragma unroll
+    for (int g = g0; g < g1; ++g)
+        top4_insert(cl, embed_lid(group_max(acc, g), keep_mask, gidbase + static_cast<unsigned>(g)));
+}
+
+// one 32-row block of the tile: 9 k-chunks x 2 query blocks = 18 MFMAs, selecting the previous
+// block's accumulators (p0/p1, row-id base pbase) in between
+template <bool EPI>
+__device__ __forceinline__ void h_block(const _Float16* __restrict__ tb, const f16x8 (&qf)[2][H_NCH], f32x16& a0,
+                                        f32x16& a1, const f32x16& p0, const f32x16& p1, unsigned pbase,
+                                        unsigned keep_mask, f32x4 (&cl)[2])
+{
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // A fragments run three chunks (= 6 MFMAs, ~190 cycles) ahead of their use: one chunk is only
+    // 64 pipe cycles, less than an LDS round trip
+    f16x8 ring[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ring[c] = *reinterpret_cast<const f16x8*>(tb + 16 * c);
+#pragma unroll
+    for (int c = 0; c < H_NCH; ++c) {
+        const f16x8 x = ring[c % 3];
+        if (c + 3 < H_NCH) ring[c % 3] = *reinterpret_cast<const f16x8*>(tb + 16 * (c + 3));
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, qf[0][c], c == 0 ? zero : a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, qf[1][c], c == 0 ? zero : a1, 0, 0, 0);
+        if (EPI && c >= 1) {                      // 8 row groups over chunks 1..8: one per chunk
+            if (((c - 1) & 1) == 0) h_select(p0, keep_mask, pbase, cl[0], (c - 1) >> 1, ((c - 1) >> 1) + 1);
+            else h_select(p1, keep_mask, pbase, cl[1], (c - 1) >> 1, ((c - 1) >> 1) + 1);
+            asm volatile("" : "+v"(cl[0][0]), "+v"(cl[0][1]), "+v"(cl[0][2]), "+v"(cl[0][3]), "+v"(cl[1][0]),
+                         "+v"(cl[1][1]), "+v"(cl[1][2]), "+v"(cl[1][3]));
+        }
+    }
+}
+
+// mode: 0 = run always (hint), 1 = run only if prep16 found the data eligible (auto)
+__global__ __launch_bounds__(256, 2) void knn_l2_mfma_f16(const _Float16* __restrict__ Qh,
+                                                          const _Float16* __restrict__ Th, int nq, int nt,
+                                                          int tiles_per_split, unsigned keep_mask,
+                                                          float* __restrict__ cand_val, int slots,
+                                                          const unsigned long long* __restrict__ stats,
+                                                          unsigned epoch, int mode)
+{
+    if (mode == 1) {
+        const unsigned long long s1 = stats[1];
+        if (static_cast<unsigned>(s1 >> 32) == epoch && (s1 & 2ull)) return;      // f32 route takes over
+    }
+    extern __shared__ __attribute__((aligned(16))) _Float16 hsm[];                // [2][H_TT][H_LDS_ROW]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int qbase = blockIdx.x * H_QB + wave * 64;
+
+    f16x8 qf[2][H_NCH];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int c = 0; c < H_NCH; ++c)
+            qf[qb][c] = *reinterpret_cast<const f16x8*>(Qh + static_cast<size_t>(qbase + 32 * qb + r) * H_ROW + 16 * c + 8 * h);
+    // make the fragments opaque: hipcc otherwise treats the loads as rematerialisable and re-reads
+    // half of them from global memory inside the tile loop (18 loads + waits per tile)
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int c = 0; c < H_NCH; ++c) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 t = __builtin_bit_cast(u32x4, qf[qb][c]);
+            asm volatile("" : "+v"(t));
+            qf[qb][c] = __builtin_bit_cast(f16x8, t);
+        }
+
+    const int ntiles = (nt + H_TT - 1) / H_TT;
+    const int tile0 = blockIdx.y * tiles_per_split;
+    int tile1 = tile0 + tiles_per_split;
+    if (tile1 > ntiles) tile1 = ntiles;
+    f32x4 cl[2] = {{-KNN_BIG, -KNN_BIG, -KNN_BIG, -KNN_BIG}, {-KNN_BIG, -KNN_BIG, -KNN_BIG, -KNN_BIG}};
+
+    HTile st;
+
+    if (tile0 < tile1) {
+        st.load(Th, tile0, tid);
+        st.store(hsm, 0, tid);
+        __syncthreads();
+        f32x16 A0, A1, B0, B1;
+        for (int tix = 0; tix < tile1 - tile0; ++tix) {
+            const int buf = tix & 1;
+            const _Float16* tb = hsm + (buf * H_TT + r) * H_LDS_ROW + 8 * h;
+            const unsigned lb = static_cast<unsigned>(tix) * 16u;          // group ids of this tile: lb + 4*blk + g
+            // the pad rows of Th cover a whole tile past the last one, so the look-ahead load is safe
+            st.load(Th, tile0 + tix + 1 < ntiles ? tile0 + tix + 1 : tile0 + tix, tid);
+            if (tix == 0) h_block<false>(tb, qf, A0, A1, A0, A1, 0u, keep_mask, cl);
+            else h_block<true>(tb, qf, A0, A1, B0, B1, lb - 4u, keep_mask, cl);                  // B = block 3 of tile-1
+            h_block<true>(tb + 32 * H_LDS_ROW, qf, B0, B1, A0, A1, lb, keep_mask, cl);
+            h_block<true>(tb + 64 * H_LDS_ROW, qf, A0, A1, B0, B1, lb + 4u, keep_mask, cl);
+            st.store(hsm, buf ^ 1, tid);
+            h_block<true>(tb + 96 * H_LDS_ROW, qf, B0, B1, A0, A1, lb + 8u, keep_mask, cl);
+            __syncthreads();
+        }
+        const unsigned lb = static_cast<unsigned>(tile1 - tile0 - 1) * 16u + 12u;
+        h_select(B0, keep_mask, lb, cl[0], 0, 4);
+        h_select(B1, keep_mask, lb, cl[1], 0, 4);
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int q = qbase + 32 * qb + r;
+        if (q < nq) *reinterpret_cast<f32x4*>(cand_val + static_cast<size_t>(q) * slots + (blockIdx.y * 2 + h) * KNN_C) = cl[qb];
+    }
+}
+
+
+template <int NCH, bool FULL, int TT>
+int launch_mfma(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt, int dim, const float* tnorm, int splits,
+                int tiles_per_split, unsigned keep_mask, float* cval, int slots, const unsigned long long* stats,
+                unsigned epoch, int only_if_ineligible)
+{
+    constexpr int LDT = NCH * 8 + 4;
+    const size_t lds = 2 * TT * LDT * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        PM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_l2_mfma<NCH, FULL, TT>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        attr_done = true;
+    }
+    dim3 grid((nq + QB - 1) / QB, splits);
+    pm::ScopedKernelTime t(ctx, "knn_l2_mfma");
+    hipLaunchKernelGGL((knn_l2_mfma<NCH, FULL, TT>), grid, dim3(256), lds, ctx->stream, dq, dt, tnorm, nq, nt, dim,
+                       tiles_per_split, keep_mask, cval, slots, stats, epoch, only_if_ineligible);
+    PM_HIP_CHECK(hipGetLastError());
+    return PM_OK;
+}
+
+}  // namespace
+
+int launch_coarse_f32(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt, int dim, const float* tnorm,
+                      int splits, int tiles_per_split, unsigned keep_mask, float* cval, int slots,
+                      const unsigned long long* stats, unsigned epoch, int only_if_ineligible)
+{
+#define PM_LAUNCH_MFMA(NCH_, FULL_)                                                                              \
+    launch_mfma<NCH_, FULL_, TT32>(ctx, dq, nq, dt, nt, dim, tnorm, splits, tiles_per_split, keep_mask, cval, slots, \
+                                   stats, epoch, only_if_ineligible)
+    if (dim == 128) return PM_LAUNCH_MFMA(16, true);
+    if (dim == 64) return PM_LAUNCH_MFMA(8, true);
+    if (dim == 32) return PM_LAUNCH_MFMA(4, true);
+    if (dim < 32) return PM_LAUNCH_MFMA(4, false);
+    if (dim < 64) return PM_LAUNCH_MFMA(8, false);
+    return PM_LAUNCH_MFMA(16, false);
+#undef PM_LAUNCH_MFMA
+}
+
+int launch_coarse_f16(pm_ctx* ctx, const _Float16* Qh, const _Float16* Th, int nq, int nq_pad, int nt, int splits,
+                      int tiles_per_split, unsigned keep_mask, float* cval, int slots,
+                      const unsigned long long* stats, unsigned epoch, int mode)
+{
+    const size_t lds = sizeof(_Float16) * 2 * H_TT * H_LDS_ROW;
+    static bool attr_done = false;
+    if (!attr_done) {
+        PM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_l2_mfma_f16),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        attr_done = true;
+    }
+    pm::ScopedKernelTime t(ctx, "knn_l2_mfma_f16");
+    hipLaunchKernelGGL(knn_l2_mfma_f16, dim3(nq_pad / H_QB, splits), dim3(256), lds, ctx->stream, Qh, Th, nq, nt,
+                       tiles_per_split, keep_mask, cval, slots, stats, epoch, mode);
+    PM_HIP_CHECK(hipGetLastError());
+    return PM_OK;
+}
+
+}  // namespace pm_knn

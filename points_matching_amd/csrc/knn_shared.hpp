@@ -1,0 +1,39 @@
+// knn_shared.hpp — constants and entry points shared by the two translation units of the L2
+// matcher: knn_l2.hip (prep, refinement, exact kernel, C ABI) and knn_coarse.hip (the two MFMA
+// coarse kernels, built with -ffinite-math-only so that the selection can use the plain
+// max/med3 builtins: no canonicalising v_max per operand, and MFMA->VALU read hazards stay under
+// the compiler's hazard recogniser instead of hand-placed inline asm).
+#pragma once
+#include "pm_common.hpp"
+
+namespace pm_knn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int KNN_C = 4;          // coarse candidates kept per (query, split, lane-half)
+constexpr int QB = 128;           // queries per workgroup, f32 route (4 waves x 32)
+constexpr int TT32 = 64;          // train rows per LDS tile, f32 route
+constexpr float KNN_BIG = 3.0e38f;   // finite sentinel: stays finite under the id insert
+
+// f16 route (integer-valued descriptors)
+constexpr int H_DP = 128;               // data columns
+constexpr int H_ROW = H_DP + 16;        // halfs per global row (288 B): data + seed chunk
+constexpr int H_LDS_ROW = H_ROW + 8;    // halfs per LDS row (304 B: 16 rows of a lane group hit 16 slots)
+constexpr int H_NCH = H_ROW / 16;       // 9 k-chunks of 16
+constexpr int H_TT = 128;               // train rows per tile
+constexpr int H_QB = 256;               // queries per workgroup (4 waves x 64)
+constexpr float H_MAXABS = 361.f;       // 128 * 361^2 < 2^24
+
+// Enqueue the f32-MFMA coarse pass (dim % 4 == 0, dim <= 128).  only_if_ineligible != 0: the
+// kernel runs only when prep16 flagged the data as not f16-eligible (auto route).
+int launch_coarse_f32(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt, int dim, const float* tnorm,
+                      int splits, int tiles_per_split, unsigned keep_mask, float* cval, int slots,
+                      const unsigned long long* stats, unsigned epoch, int only_if_ineligible);
+// Enqueue the exact f16-MFMA coarse pass on the padded f16 copies.  mode 1: run only if eligible.
+int launch_coarse_f16(pm_ctx* ctx, const _Float16* Qh, const _Float16* Th, int nq, int nq_pad, int nt, int splits,
+                      int tiles_per_split, unsigned keep_mask, float* cval, int slots,
+                      const unsigned long long* stats, unsigned epoch, int mode);
+
+}  // namespace pm_knn
