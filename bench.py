@@ -44,7 +44,11 @@ def main():
     ap.add_argument("--nt", type=int, default=8192)
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--hyps", type=int, default=10000)
-    ap.add_argument("--kind", default="sift", choices=["sift", "surf"])
+    ap.add_argument("--kind", default="sift", choices=["sift", "surf", "orb"],
+                    help="descriptor family: sift (u8-valued f32, BASELINE C3), surf (general f32), orb (256-bit, C4)")
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4"],
+                    help="BASELINE config: c3 (default, headline), c2 = 2k x 2k SIFT latency case, "
+                         "c4 = 32k x 32k ORB-256 + 100k hypotheses (per GPU: the multi-GPU run shards it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
@@ -66,22 +70,28 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
 
+    if args.workload == "c2":
+        args.nq = args.nt = 2048
+    elif args.workload == "c4":
+        args.nq = args.nt = 32768
+        args.kind, args.dim, args.hyps = "orb", 32, 100000
     nq, nt, dim, H, K = args.nq, args.nt, args.dim, args.hyps, 2
+    hamming = args.kind == "orb"
     ratio, thresh, seed = 0.8, 1.0, 0x5EED
     # A SIFT matcher knows its descriptors are u8-valued floats: state it, so that only the exact
     # f16-MFMA coarse route is enqueued (the claim is verified on the device).  Other kinds: auto.
     knn_flags = pm.api.PM_KNN_HINT_INTEGER if args.kind == "sift" else 0
-    w = synth.pair_workload(nq, nt, dim, seed=0xC3, rank=rank, kind=args.kind)
+    w = synth.pair_workload(nq, nt, dim, seed=0xC4 if hamming else 0xC3, rank=rank, kind=args.kind)
 
     ctx = pm.Context(local_rank)
     stream = torch.cuda.Stream(device=dev)      # a real (non-null) stream shared by torch and the library
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
 
-    d_q = torch.from_numpy(w["q"]).to(dev)
-    d_t = torch.from_numpy(w["t"]).to(dev)
-    d_kp1 = torch.from_numpy(w["kp1"]).to(dev)
-    d_kp2 = torch.from_numpy(w["kp2"]).to(dev)
+    d_q = torch.from_numpy(np.ascontiguousarray(w["q"])).to(dev)
+    d_t = torch.from_numpy(np.ascontiguousarray(w["t"])).to(dev)
+    d_kp1 = torch.from_numpy(np.ascontiguousarray(w["kp1"])).to(dev)
+    d_kp2 = torch.from_numpy(np.ascontiguousarray(w["kp2"])).to(dev)
     d_knn = torch.empty((nq, K, 4), dtype=torch.int32, device=dev)
     d_good = torch.empty((nq, 4), dtype=torch.int32, device=dev)
     d_xy1 = torch.zeros((nq, 2), dtype=torch.float32, device=dev)
@@ -106,7 +116,10 @@ def main():
     def step(e=None):
         if e:
             e[0].record(stream)
-        ctx.bf_knn_l2_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, K, d_knn.data_ptr(), knn_flags)
+        if hamming:
+            ctx.bf_knn_hamming_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, K, d_knn.data_ptr())
+        else:
+            ctx.bf_knn_l2_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, K, d_knn.data_ptr(), knn_flags)
         ctx.filter_ratio_gather_dev(d_knn.data_ptr(), nq, K, ratio, d_kp1.data_ptr(), d_kp2.data_ptr(),
                                     d_good.data_ptr(), d_xy1.data_ptr(), d_xy2.data_ptr(), d_n.data_ptr())
         if e:
@@ -164,27 +177,31 @@ def main():
         step()
     fence()
     kern = {}
-    for name in ("knn_l2_prep", "knn_l2_mfma_f16", "knn_l2_mfma", "knn_l2_refine", "filter_gather", "ransac_solve", "ransac_score",
+    for name in ("knn_l2_prep", "knn_l2_mfma_f16", "knn_l2_mfma", "knn_l2_refine", "knn_hamming",
+                 "knn_hamming_merge", "filter_gather", "ransac_solve", "ransac_score",
                  "ransac_select", "ransac_final", "concat_points"):
         ms, cnt = ctx.timing_get(name)
         if cnt:
             kern[name] = round(ms * 1e3, 2)           # microseconds
     ctx.timing_enable(False)
     # diagnostics of the coarse/refine split (a kNN call on its own, so the arena still holds them)
-    ctx.knn_diag_enable(True)
-    ctx.bf_knn_l2_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, K, d_knn.data_ptr(), knn_flags)
-    kstats = ctx.knn_stats()
-    ctx.knn_diag_enable(False)
-    # the general-float coarse route (f32-input MFMA) on the same data, for its own roofline line
-    ctx.timing_enable(True)
-    ctx.timing_reset()
-    for _ in range(args.steps):
-        ctx.bf_knn_l2_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, K, d_knn.data_ptr(), pm.api.PM_KNN_FORCE_F32)
-    fence()
-    f32_route_us = ctx.timing_get("knn_l2_mfma")[0] * 1e3
-    ctx.timing_enable(False)
-    ctx.bf_knn_l2_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, K, d_knn.data_ptr(), knn_flags)
-    fence()
+    kstats, f32_route_us = None, 0.0
+    if not hamming:
+        ctx.knn_diag_enable(True)
+        ctx.bf_knn_l2_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, K, d_knn.data_ptr(), knn_flags)
+        kstats = ctx.knn_stats()
+        ctx.knn_diag_enable(False)
+        # the general-float coarse route (f32-input MFMA) on the same data, for its own roofline line
+        ctx.timing_enable(True)
+        ctx.timing_reset()
+        for _ in range(args.steps):
+            ctx.bf_knn_l2_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, K, d_knn.data_ptr(),
+                              pm.api.PM_KNN_FORCE_F32)
+        fence()
+        f32_route_us = ctx.timing_get("knn_l2_mfma")[0] * 1e3
+        ctx.timing_enable(False)
+        ctx.bf_knn_l2_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, K, d_knn.data_ptr(), knn_flags)
+        fence()
 
     # ---- parity spot check against the CPU oracle (untimed; checker only)
     parity = "skipped"
@@ -192,7 +209,7 @@ def main():
         from oracle import pm_oracle as O
         got = d_knn.cpu().numpy().view(pm.MATCH_DTYPE).reshape(nq, K)
         rows = np.random.default_rng(0).permutation(nq)[:256]
-        want = O.bf_knn_l2(w["q"][rows], w["t"], K, nthreads=8)
+        want = (O.bf_knn_hamming if hamming else O.bf_knn_l2)(w["q"][rows], w["t"], K, nthreads=8)
         ok = (got["trainIdx"][rows] == want["trainIdx"]).all() and \
              (got["distance"][rows].view(np.uint32) == want["distance"].view(np.uint32)).all()
         xs1 = (a_xy1 if world > 1 else d_xy1)[:n_m].cpu().numpy()
@@ -215,11 +232,15 @@ def main():
         "metric": "descriptor-pair distances/s (BF-L2 2-NN + ratio stage); RANSAC hypotheses/s in `ransac`",
         "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 in/out; coarse pass f16xf16->f32 MFMA (exact for u8-valued data), refinement f32", "data": "synthetic",
-        "config": {"workload": "C3: %dx%d SIFT-%d f32 BF-L2 2-NN + ratio 0.8 + %d-hypothesis RANSAC-F (8-point, "
+        "dtype": "u32 xor/popcount" if hamming else "f32 in/out; coarse pass f16xf16->f32 MFMA (exact for u8-valued data), refinement f32",
+        "data": "synthetic",
+        "config": {"workload": "%s: %dx%d %s BF-%s 2-NN + ratio 0.8 + %d-hypothesis RANSAC-F (8-point, "
                                "Sampson, tau=1px) per image pair; N>1: query rows and hypothesis ids sharded"
-                               % (nq, nt, dim, H), "descriptors": args.kind, "k": K,
-                   "coarse_route": "f16-MFMA (integer hint, device-verified)" if knn_flags else "auto"},
+                               % (args.workload.upper(), nq, nt,
+                                  "ORB-%d binary" % (8 * dim) if hamming else "SIFT-%d f32" % dim,
+                                  "Hamming" if hamming else "L2", H), "descriptors": args.kind, "k": K,
+                   "coarse_route": "n/a (Hamming)" if hamming else
+                                   "f16-MFMA (integer hint, device-verified)" if knn_flags else "auto"},
         "stage_ms": {"match": match_ms, "ransac_and_exchange": rest_ms},
         "ransac": {"hyp_per_s": hyp_per_s, "hypotheses": H, "n_matches": n_m, "inliers": n_inl,
                    "best_hyp": pm.api.ransac_key_hyp(key) if key else None},
@@ -227,7 +248,15 @@ def main():
     }
     # roofline of the dominant kernel (algorithmic 2*D flop per descriptor pair)
     flops = 2.0 * dim * nq * nt
-    if kern.get("knn_l2_mfma_f16", 0) > kern.get("knn_l2_mfma", 0):
+    if hamming and "knn_hamming" in kern:
+        # 16 integer VALU ops per pair (8 x v_xor_b32 + 8 x v_bcnt_u32_b32 at 32 B); one wave64 VALU
+        # instruction occupies its SIMD 4 cycles: 1024 SIMDs * 64 lanes * 2.4 GHz / 4 = 3.93e13 lane-ops/s
+        ops = 16.0 * nq * nt
+        ach = ops / (kern["knn_hamming"] * 1e-6) / 1e12
+        out["roofline"] = {"kernel": "knn_hamming_scan", "bound": "valu-int", "achieved": ach, "peak": 39.3,
+                           "unit": "Tlane-op/s", "frac": ach / 39.3, "traffic": None,
+                           "dtype": "u32 xor + popcount on the VALU (v_xor_b32, v_bcnt_u32_b32)"}
+    elif kern.get("knn_l2_mfma_f16", 0) > kern.get("knn_l2_mfma", 0):
         ach = flops / (kern["knn_l2_mfma_f16"] * 1e-6) / 1e12
         out["roofline"] = {"kernel": "knn_l2_mfma_f16", "bound": "mfma", "achieved": ach, "peak": PEAK_F16_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": ach / PEAK_F16_MFMA_TFLOPS, "traffic": None,
@@ -255,9 +284,10 @@ def main():
         from oracle import pm_oracle as O
         sample_q = min(nq, 2048)
         t0 = time.perf_counter()
-        m = O.bf_knn_l2(w["q"][:sample_q], w["t"], K, nthreads=1)
+        knn_cpu = O.bf_knn_hamming if hamming else O.bf_knn_l2
+        m = knn_cpu(w["q"][:sample_q], w["t"], K, nthreads=1)
         t_knn = time.perf_counter() - t0
-        good = O.filter_ratio(O.bf_knn_l2(w["q"], w["t"], K, nthreads=os.cpu_count() or 1), ratio)
+        good = O.filter_ratio(knn_cpu(w["q"], w["t"], K, nthreads=os.cpu_count() or 1), ratio)
         xs1 = O.gather_points(w["kp1"], good["queryIdx"])
         xs2 = O.gather_points(w["kp2"], good["trainIdx"])
         t0 = time.perf_counter()

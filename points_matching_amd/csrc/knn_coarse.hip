@@ -4,6 +4,8 @@
 //
 // Built with -ffinite-math-only (see knn_shared.hpp).  Nothing in this file decides a result bit:
 // the coarse values only nominate candidate rows for the canonical refinement.
+#include <cstdlib>
+
 #include "knn_shared.hpp"
 
 namespace pm_knn {
@@ -281,16 +283,19 @@ __global__ __launch_bounds__(256, (TT == 64 ? 2 : 1)) void knn_l2_mfma(
 // MFMAs), walks the 128-row tile one 32-row block at a time and selects block b-1 between the
 // MFMAs of block b, with two alternating accumulator sets.
 // ---------------------------------------------------------------------------------------------
-// a tile = 128 rows x 288 B = 2304 x 16 B: nine 16-byte pieces per thread, staged through registers
+// a tile = 128 rows x 288 B = 2304 x 16 B, staged through registers by THREADS threads
+template <int THREADS>
 struct HTile {
-    static constexpr int PIECES = H_TT * (H_ROW / 8) / 256;
-    static_assert(H_TT * (H_ROW / 8) % 256 == 0, "tile must split evenly over the workgroup");
+    static constexpr int TOTAL = H_TT * (H_ROW / 8);
+    static constexpr int PIECES = (TOTAL + THREADS - 1) / THREADS;
+    static constexpr bool EVEN = TOTAL % THREADS == 0;
     uint4 stg[PIECES];
     __device__ __forceinline__ void load(const _Float16* __restrict__ Th, int tile, int tid)
     {
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
-            const int f = tid + 256 * i;
+            int f = tid + THREADS * i;
+            if (!EVEN) f = f < TOTAL ? f : TOTAL - 1;          // clamped: the load stays unconditional
             const int row = f / (H_ROW / 8), c8 = f % (H_ROW / 8);
             stg[i] = *reinterpret_cast<const uint4*>(Th + static_cast<size_t>(tile * H_TT + row) * H_ROW + 8 * c8);
         }
@@ -299,14 +304,14 @@ struct HTile {
     {
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
-            const int f = tid + 256 * i;
+            const int f = tid + THREADS * i;
             const int row = f / (H_ROW / 8), c8 = f % (H_ROW / 8);
-            *reinterpret_cast<uint4*>(hsm + (buf * H_TT + row) * H_LDS_ROW + 8 * c8) = stg[i];
+            if (EVEN || f < TOTAL) *reinterpret_cast<uint4*>(hsm + (buf * H_TT + row) * H_LDS_ROW + 8 * c8) = stg[i];
         }
     }
 };
 
-// keep the 4 largest row groups of this lane's stream for one of its two query columns
+// keep the 4 largest row groups of this lane's stream for one of its query columns
 __device__ __forceinline__ void h_select(const f32x16& acc, unsigned keep_mask, unsigned gidbase, f32x4& cl, int g0,
                                          int g1)
 {
@@ -315,16 +320,16 @@ __device__ __forceinline__ void h_select(const f32x16& acc, unsigned keep_mask, 
         top4_insert(cl, embed_lid(group_max(acc, g), keep_mask, gidbase + static_cast<unsigned>(g)));
 }
 
-// one 32-row block of the tile: 9 k-chunks x 2 query blocks = 18 MFMAs, selecting the previous
-// block's accumulators (p0/p1, row-id base pbase) in between
-template <bool EPI>
-__device__ __forceinline__ void h_block(const _Float16* __restrict__ tb, const f16x8 (&qf)[2][H_NCH], f32x16& a0,
-                                        f32x16& a1, const f32x16& p0, const f32x16& p1, unsigned pbase,
-                                        unsigned keep_mask, f32x4 (&cl)[2])
+// one 32-row block of the tile: 9 k-chunks x NQB query blocks of MFMAs, selecting the previous
+// block's accumulators p[] (group-id base pbase) in between, from chunk 1 on (see knn_tile_compute)
+template <int NQB, bool EPI>
+__device__ __forceinline__ void h_block(const _Float16* __restrict__ tb, const f16x8 (&qf)[NQB][H_NCH],
+                                        f32x16 (&a)[NQB], const f32x16 (&p)[NQB], unsigned pbase,
+                                        unsigned keep_mask, f32x4 (&cl)[NQB])
 {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // A fragments run three chunks (= 6 MFMAs, ~190 cycles) ahead of their use: one chunk is only
-    // 64 pipe cycles, less than an LDS round trip
+    // A fragments run three chunks ahead of their use: one chunk is only 32*NQB pipe cycles, less
+    // than an LDS round trip
     f16x8 ring[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) ring[c] = *reinterpret_cast<const f16x8*>(tb + 16 * c);
@@ -332,25 +337,34 @@ __device__ __forceinline__ void h_block(const _Float16* __restrict__ tb, const f
     for (int c = 0; c < H_NCH; ++c) {
         const f16x8 x = ring[c % 3];
         if (c + 3 < H_NCH) ring[c % 3] = *reinterpret_cast<const f16x8*>(tb + 16 * (c + 3));
-        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, qf[0][c], c == 0 ? zero : a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, qf[1][c], c == 0 ? zero : a1, 0, 0, 0);
-        if (EPI && c >= 1) {                      // 8 row groups over chunks 1..8: one per chunk
-            if (((c - 1) & 1) == 0) h_select(p0, keep_mask, pbase, cl[0], (c - 1) >> 1, ((c - 1) >> 1) + 1);
-            else h_select(p1, keep_mask, pbase, cl[1], (c - 1) >> 1, ((c - 1) >> 1) + 1);
-            asm volatile("" : "+v"(cl[0][0]), "+v"(cl[0][1]), "+v"(cl[0][2]), "+v"(cl[0][3]), "+v"(cl[1][0]),
-                         "+v"(cl[1][1]), "+v"(cl[1][2]), "+v"(cl[1][3]));
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb)
+            a[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, qf[qb][c], c == 0 ? zero : a[qb], 0, 0, 0);
+        if (EPI && c >= 1) {                      // 4*NQB row groups over chunks 1..8
+            constexpr int NGB = 4 * NQB;
+#pragma unroll
+            for (int e = (c - 1) * NGB / 8; e < c * NGB / 8; ++e)       // query column e % NQB, group e / NQB
+                h_select(p[e % NQB], keep_mask, pbase, cl[e % NQB], e / NQB, e / NQB + 1);
+            if (NQB == 2)
+                asm volatile("" : "+v"(cl[0][0]), "+v"(cl[0][1]), "+v"(cl[0][2]), "+v"(cl[0][3]), "+v"(cl[NQB - 1][0]),
+                             "+v"(cl[NQB - 1][1]), "+v"(cl[NQB - 1][2]), "+v"(cl[NQB - 1][3]));
+            else
+                asm volatile("" : "+v"(cl[0][0]), "+v"(cl[0][1]), "+v"(cl[0][2]), "+v"(cl[0][3]));
         }
     }
 }
 
+// NQB query blocks (of 32) per wave: 2 -> 4 waves per workgroup, 2 waves per SIMD (each A fragment
+// feeds two MFMAs); 1 -> 8 waves per workgroup, 4 waves per SIMD at <= 128 VGPRs (more waves to
+// cover LDS / barrier / MFMA-dependency latency).  Either way a workgroup owns H_QB = 256 queries.
 // mode: 0 = run always (hint), 1 = run only if prep16 found the data eligible (auto)
-__global__ __launch_bounds__(256, 2) void knn_l2_mfma_f16(const _Float16* __restrict__ Qh,
-                                                          const _Float16* __restrict__ Th, int nq, int nt,
-                                                          int tiles_per_split, unsigned keep_mask,
-                                                          float* __restrict__ cand_val, int slots,
-                                                          const unsigned long long* __restrict__ stats,
-                                                          unsigned epoch, int mode)
+template <int NQB>
+__global__ __launch_bounds__(H_QB / (32 * NQB) * 64, (NQB == 2 ? 2 : 4)) void knn_l2_mfma_f16(
+    const _Float16* __restrict__ Qh, const _Float16* __restrict__ Th, int nq, int nt, int tiles_per_split,
+    unsigned keep_mask, float* __restrict__ cand_val, int slots, const unsigned long long* __restrict__ stats,
+    unsigned epoch, int mode)
 {
+    constexpr int THREADS = H_QB / (32 * NQB) * 64;
     if (mode == 1) {
         const unsigned long long s1 = stats[1];
         if (static_cast<unsigned>(s1 >> 32) == epoch && (s1 & 2ull)) return;      // f32 route takes over
@@ -358,18 +372,18 @@ __global__ __launch_bounds__(256, 2) void knn_l2_mfma_f16(const _Float16* __rest
     extern __shared__ __attribute__((aligned(16))) _Float16 hsm[];                // [2][H_TT][H_LDS_ROW]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int qbase = blockIdx.x * H_QB + wave * 64;
+    const int qbase = blockIdx.x * H_QB + wave * 32 * NQB;
 
-    f16x8 qf[2][H_NCH];
+    f16x8 qf[NQB][H_NCH];
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
+    for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
         for (int c = 0; c < H_NCH; ++c)
             qf[qb][c] = *reinterpret_cast<const f16x8*>(Qh + static_cast<size_t>(qbase + 32 * qb + r) * H_ROW + 16 * c + 8 * h);
     // make the fragments opaque: hipcc otherwise treats the loads as rematerialisable and re-reads
-    // half of them from global memory inside the tile loop (18 loads + waits per tile)
+    // some of them from global memory inside the tile loop
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
+    for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
         for (int c = 0; c < H_NCH; ++c) {
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -382,40 +396,41 @@ __global__ __launch_bounds__(256, 2) void knn_l2_mfma_f16(const _Float16* __rest
     const int tile0 = blockIdx.y * tiles_per_split;
     int tile1 = tile0 + tiles_per_split;
     if (tile1 > ntiles) tile1 = ntiles;
-    f32x4 cl[2] = {{-KNN_BIG, -KNN_BIG, -KNN_BIG, -KNN_BIG}, {-KNN_BIG, -KNN_BIG, -KNN_BIG, -KNN_BIG}};
+    f32x4 cl[NQB];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) cl[qb] = f32x4{-KNN_BIG, -KNN_BIG, -KNN_BIG, -KNN_BIG};
 
-    HTile st;
+    HTile<THREADS> st;
 
     if (tile0 < tile1) {
         st.load(Th, tile0, tid);
         st.store(hsm, 0, tid);
         __syncthreads();
-        f32x16 A0, A1, B0, B1;
+        f32x16 A[NQB], B[NQB];
         for (int tix = 0; tix < tile1 - tile0; ++tix) {
             const int buf = tix & 1;
             const _Float16* tb = hsm + (buf * H_TT + r) * H_LDS_ROW + 8 * h;
             const unsigned lb = static_cast<unsigned>(tix) * 16u;          // group ids of this tile: lb + 4*blk + g
-            // the pad rows of Th cover a whole tile past the last one, so the look-ahead load is safe
+            // the last tile is simply staged again: past the end nothing reads the other buffer
             st.load(Th, tile0 + tix + 1 < ntiles ? tile0 + tix + 1 : tile0 + tix, tid);
-            if (tix == 0) h_block<false>(tb, qf, A0, A1, A0, A1, 0u, keep_mask, cl);
-            else h_block<true>(tb, qf, A0, A1, B0, B1, lb - 4u, keep_mask, cl);                  // B = block 3 of tile-1
-            h_block<true>(tb + 32 * H_LDS_ROW, qf, B0, B1, A0, A1, lb, keep_mask, cl);
-            h_block<true>(tb + 64 * H_LDS_ROW, qf, A0, A1, B0, B1, lb + 4u, keep_mask, cl);
+            if (tix == 0) h_block<NQB, false>(tb, qf, A, A, 0u, keep_mask, cl);
+            else h_block<NQB, true>(tb, qf, A, B, lb - 4u, keep_mask, cl);                        // B = block 3 of tile-1
+            h_block<NQB, true>(tb + 32 * H_LDS_ROW, qf, B, A, lb, keep_mask, cl);
+            h_block<NQB, true>(tb + 64 * H_LDS_ROW, qf, A, B, lb + 4u, keep_mask, cl);
             st.store(hsm, buf ^ 1, tid);
-            h_block<true>(tb + 96 * H_LDS_ROW, qf, B0, B1, A0, A1, lb + 8u, keep_mask, cl);
+            h_block<NQB, true>(tb + 96 * H_LDS_ROW, qf, B, A, lb + 8u, keep_mask, cl);
             __syncthreads();
         }
         const unsigned lb = static_cast<unsigned>(tile1 - tile0 - 1) * 16u + 12u;
-        h_select(B0, keep_mask, lb, cl[0], 0, 4);
-        h_select(B1, keep_mask, lb, cl[1], 0, 4);
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) h_select(B[qb], keep_mask, lb, cl[qb], 0, 4);
     }
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
+    for (int qb = 0; qb < NQB; ++qb) {
         const int q = qbase + 32 * qb + r;
         if (q < nq) *reinterpret_cast<f32x4*>(cand_val + static_cast<size_t>(q) * slots + (blockIdx.y * 2 + h) * KNN_C) = cl[qb];
     }
 }
-
 
 template <int NCH, bool FULL, int TT>
 int launch_mfma(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt, int dim, const float* tnorm, int splits,
@@ -461,15 +476,24 @@ int launch_coarse_f16(pm_ctx* ctx, const _Float16* Qh, const _Float16* Th, int n
                       const unsigned long long* stats, unsigned epoch, int mode)
 {
     const size_t lds = sizeof(_Float16) * 2 * H_TT * H_LDS_ROW;
+    static const int nqb_env = [] { const char* e = getenv("PM_KNN_F16_NQB"); return e ? atoi(e) : 0; }();
+    // few tiles per workgroup: the 8-wave form covers latency better; long sweeps: the 4-wave form halves LDS reads
+    const int nqb = nqb_env == 1 || nqb_env == 2 ? nqb_env : (tiles_per_split <= 8 ? 1 : 2);
     static bool attr_done = false;
     if (!attr_done) {
-        PM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_l2_mfma_f16),
+        PM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_l2_mfma_f16<1>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        PM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_l2_mfma_f16<2>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
         attr_done = true;
     }
     pm::ScopedKernelTime t(ctx, "knn_l2_mfma_f16");
-    hipLaunchKernelGGL(knn_l2_mfma_f16, dim3(nq_pad / H_QB, splits), dim3(256), lds, ctx->stream, Qh, Th, nq, nt,
-                       tiles_per_split, keep_mask, cval, slots, stats, epoch, mode);
+    if (nqb == 2)
+        hipLaunchKernelGGL(knn_l2_mfma_f16<2>, dim3(nq_pad / H_QB, splits), dim3(256), lds, ctx->stream, Qh, Th, nq, nt,
+                           tiles_per_split, keep_mask, cval, slots, stats, epoch, mode);
+    else
+        hipLaunchKernelGGL(knn_l2_mfma_f16<1>, dim3(nq_pad / H_QB, splits), dim3(512), lds, ctx->stream, Qh, Th, nq, nt,
+                           tiles_per_split, keep_mask, cval, slots, stats, epoch, mode);
     PM_HIP_CHECK(hipGetLastError());
     return PM_OK;
 }

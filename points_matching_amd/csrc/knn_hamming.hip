@@ -124,7 +124,7 @@ int run_passes(pm_ctx* ctx, const uint32_t* dq, int nq, const uint32_t* dt, int 
     const int qblocks = (nq + 255) / 256;
     int splits = nt > 0 ? (8 * ctx->n_cu + qblocks - 1) / qblocks : 1;   // ~8 waves per SIMD
     if (splits > (nt + 63) / 64) splits = (nt + 63) / 64;
-    if (splits > 256) splits = 256;
+    if (splits > 32) splits = 32;            // the merge walks splits*KL entries per query serially
     if (splits < 1) splits = 1;
     int rows_per_split = (nt + splits - 1) / splits;
     if (rows_per_split < 1) rows_per_split = 1;

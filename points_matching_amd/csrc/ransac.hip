@@ -10,7 +10,10 @@
 //   ransac_score   lane = hypothesis (F in 9 VGPRs), correspondences are wave-uniform and arrive
 //                  as scalar operands; grid = hypothesis blocks x correspondence chunks, partial
 //                  inlier counts meet in one integer atomicAdd per (lane, chunk)
-//   ransac_select  key = (inliers << 32) | (0xFFFFFFFF - h), block max, one 64-bit atomicMax
+//                  Single-shard runs finish inside this launch: the last workgroup of a hypothesis
+//                  block reduces the block's best key = (inliers << 32) | (0xFFFFFFFF - h), the last
+//                  block overall picks the winner, publishes its stored fp64 model and the mask.
+//   ransac_select  (sharded runs) key only: block max, one 64-bit atomicMax; the caller all-reduces it
 //   ransac_final_* re-derive F (fp64) and the inlier mask of ONE hypothesis id — every rank of a
 //                  multi-GPU run does this for the all-reduced winner, so no model is broadcast.
 //
@@ -279,10 +282,12 @@ __global__ __launch_bounds__(64) void ransac_solve(const float* __restrict__ xy1
                                                    int n_max, const int* __restrict__ d_n, uint64_t seed,
                                                    int64_t hyp_begin, int nh, float* __restrict__ models,
                                                    double* __restrict__ models64, int* __restrict__ counts,
-                                                   unsigned long long* __restrict__ key)
+                                                   unsigned long long* __restrict__ key, int* __restrict__ tickets,
+                                                   int n_tickets)
 {
     const int t = blockIdx.x * 64 + threadIdx.x;
     if (t == 0) *key = 0ull;
+    if (t < n_tickets) tickets[t] = 0;          // arrival counters of the fused scorer (grid >= n_tickets threads)
     if (t >= nh) return;
     counts[t] = 0;
     const int n = resolve_n(n_max, d_n);
@@ -296,6 +301,51 @@ __global__ __launch_bounds__(64) void ransac_solve(const float* __restrict__ xy1
     double* m64 = models64 + static_cast<size_t>(t) * 9;
 #pragma unroll
     for (int i = 0; i < 9; ++i) m64[i] = F[i];
+}
+
+__device__ __forceinline__ unsigned long long hyp_key(const float* __restrict__ models, const int* __restrict__ counts,
+                                                      int t, int64_t hyp_begin)
+{
+    const float valid = models[static_cast<size_t>(t) * MODEL_STRIDE + 9];   // both loads unconditional
+    const uint32_t cnt = static_cast<uint32_t>(counts[t]);
+    const uint32_t h = static_cast<uint32_t>(hyp_begin + t);
+    const unsigned long long key = (static_cast<unsigned long long>(cnt) << 32) |
+                                   static_cast<unsigned long long>(0xFFFFFFFFu - h);
+    return valid != 0.f ? key : 0ull;
+}
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long key)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long w = __shfl_xor(key, o, 64);
+        key = w > key ? w : key;
+    }
+    return key;
+}
+
+// result block in device memory
+struct FinalOut {
+    double F[9];
+    int valid;
+    int n_inliers;
+    float F32[9];
+    int pad;
+};
+
+__device__ __forceinline__ void publish_model(FinalOut* __restrict__ fo, double* __restrict__ F_out,
+                                              int* __restrict__ n_out, const double (&F)[9], bool ok)
+{
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const double v = ok ? F[i] : 0.0;
+        fo->F[i] = v;
+        fo->F32[i] = static_cast<float>(v);
+        if (F_out) F_out[i] = v;
+    }
+    fo->valid = ok ? 1 : 0;
+    fo->n_inliers = 0;
+    if (n_out) *n_out = 0;
 }
 
 constexpr int SCORE_CHUNK = 256;      // correspondences staged per workgroup (4 KB of LDS)
@@ -330,11 +380,29 @@ __device__ __forceinline__ int inlier32_x2(const float (&f)[9], f32x2 x, f32x2 y
     }
 }
 
-template <int KIND>
+// What the fused (single-shard) scorer needs to finish the run inside the same launch.
+struct FusedTail {
+    const double* models64;
+    int* tickets;                 // [0] = hypothesis blocks done, [1 + b] = chunks of block b done
+    unsigned long long* best;
+    FinalOut* fo;
+    double* F_out;                // may be null
+    uint8_t* mask;
+    int* n_out;                   // may be null
+    int64_t hyp_begin;
+};
+
+// FUSED: the workgroup that completes a hypothesis block (last of its chunks to arrive) reduces the
+// block's best key; the workgroup that completes the last block picks the winner, publishes its
+// stored fp64 model and writes the inlier mask — score, pick and mask in ONE launch.  Arrival
+// order is whatever it is: every counter is an agent-scope atomic, each wave drains its own
+// atomics (s_waitcnt vmcnt(0)) before the workgroup's ticket is drawn, and the finishing
+// workgroups read counters/keys with agent-scope loads (CDNA guide, Guideline 16).
+template <int KIND, bool FUSED>
 __global__ __launch_bounds__(256) void ransac_score(const float* __restrict__ xy1, const float* __restrict__ xy2,
                                                     int n_max, const int* __restrict__ d_n, int chunk_len,
                                                     const float* __restrict__ models, int nh, float thr2,
-                                                    int* __restrict__ counts)
+                                                    int* __restrict__ counts, FusedTail ft)
 {
     // pair p of the chunk: pts[2p] = (x_a, x_b, y_a, y_b), pts[2p+1] = (x'_a, x'_b, y'_a, y'_b)
     __shared__ __attribute__((aligned(16))) float pts[SCORE_CHUNK * 4];
@@ -382,27 +450,77 @@ __global__ __launch_bounds__(256) void ransac_score(const float* __restrict__ xy
         cnt += inlier32_x2<KIND>(f, f32x2{u0[0], u0[1]}, f32x2{u0[2], u0[3]}, f32x2{v0[0], v0[1]}, f32x2{v0[2], v0[3]}, thr2);
     }
     if (t < nh && cnt) atomicAdd(&counts[t], cnt);
-}
+    if (!FUSED) return;
 
-__device__ __forceinline__ unsigned long long hyp_key(const float* __restrict__ models, const int* __restrict__ counts,
-                                                      int t, int64_t hyp_begin)
-{
-    const float valid = models[static_cast<size_t>(t) * MODEL_STRIDE + 9];   // both loads unconditional
-    const uint32_t cnt = static_cast<uint32_t>(counts[t]);
-    const uint32_t h = static_cast<uint32_t>(hyp_begin + t);
-    const unsigned long long key = (static_cast<unsigned long long>(cnt) << 32) |
-                                   static_cast<unsigned long long>(0xFFFFFFFFu - h);
-    return valid != 0.f ? key : 0ull;
-}
-
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long key)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long w = __shfl_xor(key, o, 64);
-        key = w > key ? w : key;
+    __shared__ int role;
+    __shared__ unsigned long long wkey[4];
+    __shared__ float Fsh[9];
+    __shared__ int vsh;
+    __shared__ int wcnt[4];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's counter updates are performed
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tk = __hip_atomic_fetch_add(&ft.tickets[1 + blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        role = tk == static_cast<int>(gridDim.y) - 1 ? 1 : 0;
     }
-    return key;
+    __syncthreads();
+    if (role == 0) return;
+    // ---- last chunk of this hypothesis block: the block's best key
+    unsigned long long key = 0ull;
+    if (t < nh && models[static_cast<size_t>(t) * MODEL_STRIDE + 9] != 0.f) {
+        const uint32_t c = static_cast<uint32_t>(__hip_atomic_load(&counts[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        key = (static_cast<unsigned long long>(c) << 32) |
+              static_cast<unsigned long long>(0xFFFFFFFFu - static_cast<uint32_t>(ft.hyp_begin + t));
+    }
+    key = wave_max_u64(key);
+    if ((threadIdx.x & 63) == 0) wkey[threadIdx.x >> 6] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) key = wkey[w] > key ? wkey[w] : key;
+        if (key) atomicMax(ft.best, key);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int g = __hip_atomic_fetch_add(&ft.tickets[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        role = g == static_cast<int>(gridDim.x) - 1 ? 2 : 0;
+    }
+    __syncthreads();
+    if (role != 2) return;
+    // ---- every block is done: pick the winner, publish its stored fp64 model, write the mask
+    if (threadIdx.x == 0) {
+        const unsigned long long k = __hip_atomic_load(ft.best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool ok = k != 0ull && n >= 8;
+        const int tw = ok ? static_cast<int>(static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(k)) - ft.hyp_begin) : 0;
+        double F[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) F[i] = ok ? ft.models64[static_cast<size_t>(tw) * 9 + i] : 0.0;
+        publish_model(ft.fo, ft.F_out, nullptr, F, ok);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Fsh[i] = ok ? static_cast<float>(F[i]) : 0.f;
+        vsh = ok ? 1 : 0;
+    }
+    __syncthreads();
+    float fw[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) fw[i] = Fsh[i];
+    int mine = 0;
+    for (int i = threadIdx.x; i < n_max; i += 256) {
+        bool in = false;
+        if (i < n && vsh) {
+            const float2 a = *reinterpret_cast<const float2*>(xy1 + 2 * static_cast<size_t>(i));
+            const float2 b = *reinterpret_cast<const float2*>(xy2 + 2 * static_cast<size_t>(i));
+            in = inlier32<KIND>(fw, a.x, a.y, b.x, b.y, thr2);
+        }
+        ft.mask[i] = in ? 1 : 0;
+        mine += in ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        ft.fo->n_inliers = tot;
+        if (ft.n_out) *ft.n_out = tot;
+    }
 }
 
 // shard key only (multi-GPU: the caller all-reduces it)
@@ -419,65 +537,6 @@ __global__ __launch_bounds__(256) void ransac_select(const float* __restrict__ m
         unsigned long long k = wbest[0];
         for (int w = 1; w < 4; ++w) k = wbest[w] > k ? wbest[w] : k;
         if (k) atomicMax(best, k);
-    }
-}
-
-// result block in device memory
-struct FinalOut {
-    double F[9];
-    int valid;
-    int n_inliers;
-    float F32[9];
-    int pad;
-};
-
-__device__ __forceinline__ void publish_model(FinalOut* __restrict__ fo, double* __restrict__ F_out,
-                                              int* __restrict__ n_out, const double (&F)[9], bool ok)
-{
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        const double v = ok ? F[i] : 0.0;
-        fo->F[i] = v;
-        fo->F32[i] = static_cast<float>(v);
-        if (F_out) F_out[i] = v;
-    }
-    fo->valid = ok ? 1 : 0;
-    fo->n_inliers = 0;
-    if (n_out) *n_out = 0;
-}
-
-// single-shard run: pick the winner of THIS shard and publish its stored fp64 model (no second
-// solve).  One workgroup of 1024 threads strides over the shard.
-__global__ __launch_bounds__(1024) void ransac_pick(const float* __restrict__ models,
-                                                    const double* __restrict__ models64,
-                                                    const int* __restrict__ counts, int nh, int64_t hyp_begin,
-                                                    unsigned long long* __restrict__ best, FinalOut* __restrict__ fo,
-                                                    double* __restrict__ F_out, int* __restrict__ n_out)
-{
-    __shared__ unsigned long long wbest[16];
-    unsigned long long key = 0ull;
-    for (int t0 = threadIdx.x; t0 < nh; t0 += 12 * 1024) {          // 12 independent load pairs per trip
-        unsigned long long kk[12];
-#pragma unroll
-        for (int u = 0; u < 12; ++u) {
-            const int t = t0 + u * 1024;
-            kk[u] = hyp_key(models, counts, t < nh ? t : nh - 1, hyp_begin);   // clamped: a duplicate is harmless
-        }
-#pragma unroll
-        for (int u = 0; u < 12; ++u) key = kk[u] > key ? kk[u] : key;
-    }
-    key = wave_max_u64(key);
-    if ((threadIdx.x & 63) == 0) wbest[threadIdx.x >> 6] = key;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 16; ++w) key = wbest[w] > key ? wbest[w] : key;
-        *best = key;
-        double F[9];
-        const bool ok = key != 0ull;
-        const int t = ok ? static_cast<int>(static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(key)) - hyp_begin) : 0;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) F[i] = ok ? models64[static_cast<size_t>(t) * 9 + i] : 0.0;
-        publish_model(fo, F_out, n_out, F, ok);
     }
 }
 
@@ -539,6 +598,8 @@ struct ShardScratch {
     float* models;
     double* models64;
     int* counts;
+    int* tickets;
+    int n_tickets;
     FinalOut* fo;
 };
 
@@ -546,7 +607,7 @@ size_t shard_scratch_bytes(const pm_ransac_params* p)
 {
     const size_t nh = static_cast<size_t>(p->hyp_end - p->hyp_begin);
     return pm::align_up(sizeof(float) * MODEL_STRIDE * nh, 256) + pm::align_up(sizeof(double) * 9 * nh, 256) +
-           pm::align_up(sizeof(int) * nh, 256) + 512;
+           pm::align_up(sizeof(int) * nh, 256) + pm::align_up(sizeof(int) * (nh / 256 + 2), 256) + 1024;
 }
 
 int take_scratch(pm_ctx* ctx, const pm_ransac_params* p, ShardScratch& sc)
@@ -555,14 +616,17 @@ int take_scratch(pm_ctx* ctx, const pm_ransac_params* p, ShardScratch& sc)
     sc.models = static_cast<float*>(pm::arena_take(ctx, sizeof(float) * MODEL_STRIDE * nh + 16));
     sc.models64 = static_cast<double*>(pm::arena_take(ctx, sizeof(double) * 9 * nh + 16));
     sc.counts = static_cast<int*>(pm::arena_take(ctx, sizeof(int) * nh + 16));
+    sc.n_tickets = static_cast<int>((nh + 255) / 256) + 1;
+    sc.tickets = static_cast<int*>(pm::arena_take(ctx, sizeof(int) * (nh / 256 + 2)));
     sc.fo = static_cast<FinalOut*>(pm::arena_take(ctx, sizeof(FinalOut)));
-    PM_REQUIRE(sc.models && sc.models64 && sc.counts && sc.fo, PM_E_NOMEM, "scratch arena too small");
+    PM_REQUIRE(sc.models && sc.models64 && sc.counts && sc.tickets && sc.fo, PM_E_NOMEM, "scratch arena too small");
     return PM_OK;
 }
 
 // solve + score the shard.  On return (stream order) counts[] hold the inlier counts.
 int score_shard(pm_ctx* ctx, const float* dxy1, const float* dxy2, int n, const int* d_n,
-                const pm_ransac_params* p, unsigned long long* d_key, const ShardScratch& sc)
+                const pm_ransac_params* p, unsigned long long* d_key, const ShardScratch& sc,
+                const FusedTail* fused = nullptr)
 {
     const int nh = static_cast<int>(p->hyp_end - p->hyp_begin);
     if (nh == 0) {
@@ -572,7 +636,7 @@ int score_shard(pm_ctx* ctx, const float* dxy1, const float* dxy2, int n, const 
     {
         pm::ScopedKernelTime t(ctx, "ransac_solve");
         hipLaunchKernelGGL(ransac_solve, dim3((nh + 63) / 64), dim3(64), 0, ctx->stream, dxy1, dxy2, n, d_n, p->seed,
-                           p->hyp_begin, nh, sc.models, sc.models64, sc.counts, d_key);
+                           p->hyp_begin, nh, sc.models, sc.models64, sc.counts, d_key, sc.tickets, sc.n_tickets);
         PM_HIP_CHECK(hipGetLastError());
     }
     const int hb = (nh + 255) / 256;
@@ -588,12 +652,14 @@ int score_shard(pm_ctx* ctx, const float* dxy1, const float* dxy2, int n, const 
     const float thr2 = p->thresh_px * p->thresh_px;
     {
         pm::ScopedKernelTime t(ctx, "ransac_score");
-        if (p->error_kind == PM_ERR_SAMPSON)
-            hipLaunchKernelGGL(ransac_score<PM_ERR_SAMPSON>, dim3(hb, chunks), dim3(256), 0, ctx->stream, dxy1, dxy2, n,
-                               d_n, chunk_len, sc.models, nh, thr2, sc.counts);
-        else
-            hipLaunchKernelGGL(ransac_score<PM_ERR_SYM_EPIPOLAR>, dim3(hb, chunks), dim3(256), 0, ctx->stream, dxy1,
-                               dxy2, n, d_n, chunk_len, sc.models, nh, thr2, sc.counts);
+        const FusedTail none{};
+        const FusedTail& ft = fused ? *fused : none;
+#define PM_SCORE(KIND_, FUSED_)                                                                                    \
+    hipLaunchKernelGGL((ransac_score<KIND_, FUSED_>), dim3(hb, chunks), dim3(256), 0, ctx->stream, dxy1, dxy2, n, d_n, \
+                       chunk_len, sc.models, nh, thr2, sc.counts, ft)
+        if (p->error_kind == PM_ERR_SAMPSON) { if (fused) PM_SCORE(PM_ERR_SAMPSON, true); else PM_SCORE(PM_ERR_SAMPSON, false); }
+        else { if (fused) PM_SCORE(PM_ERR_SYM_EPIPOLAR, true); else PM_SCORE(PM_ERR_SYM_EPIPOLAR, false); }
+#undef PM_SCORE
         PM_HIP_CHECK(hipGetLastError());
     }
     return PM_OK;
@@ -635,16 +701,20 @@ int finalize_from_key(pm_ctx* ctx, const float* dxy1, const float* dxy2, int n, 
     return launch_mask(ctx, dxy1, dxy2, n, d_n, p, d_fo, d_mask, d_ninl);
 }
 
-// finalise the winner of the shard just scored (stored fp64 model, no second solve)
-int finalize_local(pm_ctx* ctx, const float* dxy1, const float* dxy2, int n, const int* d_n,
-                   const pm_ransac_params* p, unsigned long long* d_key, const ShardScratch& sc, double* d_F,
-                   uint8_t* d_mask, int* d_ninl)
+// single-shard run: solve, then score + pick + mask in one launch (no second solve, no extra launches)
+int run_local(pm_ctx* ctx, const float* dxy1, const float* dxy2, int n, const int* d_n, const pm_ransac_params* p,
+              unsigned long long* d_key, const ShardScratch& sc, double* d_F, uint8_t* d_mask, int* d_ninl)
 {
-    const int nh = static_cast<int>(p->hyp_end - p->hyp_begin);
-    pm::ScopedKernelTime t(ctx, "ransac_final");
-    hipLaunchKernelGGL(ransac_pick, dim3(1), dim3(1024), 0, ctx->stream, sc.models, sc.models64, sc.counts, nh,
-                       p->hyp_begin, d_key, sc.fo, d_F, d_ninl);
-    return launch_mask(ctx, dxy1, dxy2, n, d_n, p, sc.fo, d_mask, d_ninl);
+    FusedTail ft{};
+    ft.models64 = sc.models64;
+    ft.tickets = sc.tickets;
+    ft.best = d_key;
+    ft.fo = sc.fo;
+    ft.F_out = d_F;
+    ft.mask = d_mask;
+    ft.n_out = d_ninl;
+    ft.hyp_begin = p->hyp_begin;
+    return score_shard(ctx, dxy1, dxy2, n, d_n, p, d_key, sc, &ft);
 }
 
 // Shared host-pointer driver: run the shard (hyp < 0) or take the given hypothesis, then finalise.
@@ -683,12 +753,12 @@ int host_run(pm_ctx* ctx, const float* xy1, const float* xy2, int n, const pm_ra
     PM_HIP_CHECK(hipMemcpyAsync(dxy1, xy1, xyb, hipMemcpyHostToDevice, ctx->stream));
     PM_HIP_CHECK(hipMemcpyAsync(dxy2, xy2, xyb, hipMemcpyHostToDevice, ctx->stream));
     if (hyp < 0) {
-        rc = score_shard(ctx, dxy1, dxy2, n, nullptr, p, dkey, sc);
-        if (rc != PM_OK) return rc;
-        if (p->hyp_end > p->hyp_begin)
-            rc = finalize_local(ctx, dxy1, dxy2, n, nullptr, p, dkey, sc, nullptr, dmask, nullptr);
-        else
-            rc = finalize_from_key(ctx, dxy1, dxy2, n, nullptr, p, dkey, sc.fo, nullptr, dmask, nullptr);
+        if (p->hyp_end > p->hyp_begin) {
+            rc = run_local(ctx, dxy1, dxy2, n, nullptr, p, dkey, sc, nullptr, dmask, nullptr);
+        } else {
+            rc = score_shard(ctx, dxy1, dxy2, n, nullptr, p, dkey, sc);
+            if (rc == PM_OK) rc = finalize_from_key(ctx, dxy1, dxy2, n, nullptr, p, dkey, sc.fo, nullptr, dmask, nullptr);
+        }
     } else {
         const unsigned long long k = pm_ransac_key(0u, static_cast<uint32_t>(hyp)) | (1ull << 32);  // non-zero
         unsigned long long* hk = static_cast<unsigned long long*>(ctx->pinned);
@@ -786,9 +856,7 @@ extern "C" int pm_ransac_run_dev(pm_ctx* ctx, const float* d_xy1, const float* d
     if (rc != PM_OK) return rc;
     PM_REQUIRE(p->hyp_end > p->hyp_begin, PM_E_INVALID, "empty hypothesis range");
     unsigned long long* key = reinterpret_cast<unsigned long long*>(d_best_key);
-    rc = score_shard(ctx, d_xy1, d_xy2, n_max, d_n, p, key, sc);
-    if (rc != PM_OK) return rc;
-    return finalize_local(ctx, d_xy1, d_xy2, n_max, d_n, p, key, sc, d_F, d_mask, d_n_inliers);
+    return run_local(ctx, d_xy1, d_xy2, n_max, d_n, p, key, sc, d_F, d_mask, d_n_inliers);
 }
 
 extern "C" int pm_ransac_model_from_key_dev(pm_ctx* ctx, const float* d_xy1, const float* d_xy2, int n_max,

@@ -107,7 +107,7 @@ def two_view(n, seed=0xC3, outlier_frac=0.3, noise_px=0.5, width=993, height=660
     F /= np.linalg.norm(F)
     if F[2, 2] < 0:
         F = -F
-    return x1.astype(np.float32), x2.astype(np.float32), F, inl
+    return np.ascontiguousarray(x1.astype(np.float32)), np.ascontiguousarray(x2.astype(np.float32)), F, inl
 
 
 def _sift_quant(x):
@@ -187,5 +187,7 @@ def pair_workload(nq=8192, nt=8192, dim=128, seed=0xC3, rank=0, planted=0.28, ou
     perm = rq.permutation(nq)
     truth = np.full(nq, -1, np.int32)
     truth[:n_pl] = src
-    return {"q": np.ascontiguousarray(q[perm]), "t": t, "kp1": np.ascontiguousarray(kp1[perm].astype(np.float32)),
-            "kp2": kp2, "truth": truth[perm], "true_inlier": true_inlier[perm], "F_gt": F}
+    # every array C-contiguous: the device entry points take raw pointers
+    return {"q": np.ascontiguousarray(q[perm]), "t": np.ascontiguousarray(t),
+            "kp1": np.ascontiguousarray(kp1[perm].astype(np.float32)), "kp2": np.ascontiguousarray(kp2),
+            "truth": truth[perm], "true_inlier": true_inlier[perm], "F_gt": F}
