@@ -49,9 +49,18 @@ def main():
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4"],
                     help="BASELINE config: c3 (default, headline), c2 = 2k x 2k SIFT latency case, "
                          "c4 = 32k x 32k ORB-256 + 100k hypotheses (per GPU: the multi-GPU run shards it)")
+    ap.add_argument("--exercise-exchange", action="store_true",
+                    help="debugging: run the N>1 code path (all-gather, concat, key all-reduce, model from key) "
+                         "even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
+
+    # Only the JSON line may reach stdout: RCCL prints a version banner to fd 1 when it initialises,
+    # so fd 1 points at stderr until the result is ready.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -65,9 +74,14 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.exercise_exchange
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if world > 1:
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
 
     if args.workload == "c2":
@@ -102,7 +116,7 @@ def main():
     d_F = torch.zeros(9, dtype=torch.float64, device=dev)
     d_mask = torch.zeros(n_all_max, dtype=torch.uint8, device=dev)
     d_ninl = torch.zeros(1, dtype=torch.int32, device=dev)
-    if world > 1:
+    if multi:
         g_xy1 = torch.zeros((world, nq, 2), dtype=torch.float32, device=dev)
         g_xy2 = torch.zeros((world, nq, 2), dtype=torch.float32, device=dev)
         g_n = torch.zeros(world, dtype=torch.int32, device=dev)
@@ -124,14 +138,14 @@ def main():
                                     d_good.data_ptr(), d_xy1.data_ptr(), d_xy2.data_ptr(), d_n.data_ptr())
         if e:
             e[1].record(stream)
-        if world > 1:
+        if multi:
             shard.gather_blocks(d_xy1, d_xy2, d_n, g_xy1, g_xy2, g_n)
             ctx.concat_points_dev(g_xy1.data_ptr(), g_xy2.data_ptr(), g_n.data_ptr(), world, nq,
                                   a_xy1.data_ptr(), a_xy2.data_ptr(), a_n.data_ptr())
             x1, x2, nn = a_xy1, a_xy2, a_n
         else:
             x1, x2, nn = d_xy1, d_xy2, d_n
-        if world > 1:
+        if multi:
             ctx.ransac_score_devn(x1.data_ptr(), x2.data_ptr(), n_all_max, nn.data_ptr(), hb, he, thresh, seed,
                                   d_key.data_ptr())
             shard.reduce_key(d_key)                            # the single 8-byte exchange
@@ -144,7 +158,7 @@ def main():
             e[2].record(stream)
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -159,13 +173,13 @@ def main():
     wall = t1 - t0
     match_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     rest_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
-    if world > 1:
+    if multi:
         tt = torch.tensor([wall, match_ms, rest_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, match_ms, rest_ms = [float(x) for x in tt.tolist()]
     ms_per_step = wall / args.steps * 1e3
 
-    n_m = int((a_n if world > 1 else d_n).item())
+    n_m = int((a_n if multi else d_n).item())
     key = int(d_key.item())
     n_inl = int(d_ninl.item())
 
@@ -212,17 +226,19 @@ def main():
         want = (O.bf_knn_hamming if hamming else O.bf_knn_l2)(w["q"][rows], w["t"], K, nthreads=8)
         ok = (got["trainIdx"][rows] == want["trainIdx"]).all() and \
              (got["distance"][rows].view(np.uint32) == want["distance"].view(np.uint32)).all()
-        xs1 = (a_xy1 if world > 1 else d_xy1)[:n_m].cpu().numpy()
-        xs2 = (a_xy2 if world > 1 else d_xy2)[:n_m].cpu().numpy()
+        xs1 = (a_xy1 if multi else d_xy1)[:n_m].cpu().numpy()
+        xs2 = (a_xy2 if multi else d_xy2)[:n_m].cpu().numpy()
         rc, F_o, mask_o, ninl_o, key_o = O.ransac_fundamental(xs1, xs2, H, thresh, seed, nthreads=8)
         ok = ok and key_o == key and ninl_o == n_inl and (mask_o == d_mask[:n_m].cpu().numpy()).all() \
             and (F_o.reshape(9).view(np.uint64) == d_F.cpu().numpy().view(np.uint64)).all()
         parity = "ok" if ok else "MISMATCH"
 
     if rank != 0:
-        if world > 1:
+        if multi:
             dist.destroy_process_group()
         return
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
 
     pairs = float(nq) * nt * world
     value = pairs / (match_ms * 1e-3)
@@ -301,7 +317,7 @@ def main():
             "ransac_hyp_per_s": H / t_r, "host_cpus": os.cpu_count(),
         }
     print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
