@@ -191,8 +191,8 @@ def main():
         step()
     fence()
     kern = {}
-    for name in ("knn_l2_prep", "knn_l2_mfma_f16", "knn_l2_mfma", "knn_l2_refine", "knn_hamming",
-                 "knn_hamming_merge", "filter_gather", "ransac_solve", "ransac_score",
+    for name in ("knn_l2_prep", "knn_l2_mfma_f16", "knn_l2_mfma", "knn_l2_refine", "knn_hamming_expand",
+                 "knn_hamming_mfma_i8", "knn_hamming_refine", "knn_hamming", "knn_hamming_merge", "filter_gather", "ransac_solve", "ransac_score",
                  "ransac_select", "ransac_final", "concat_points"):
         ms, cnt = ctx.timing_get(name)
         if cnt:
@@ -245,10 +245,11 @@ def main():
     hyp_per_s = H / (rest_ms * 1e-3)
 
     out = {
-        "metric": "descriptor-pair distances/s (BF-L2 2-NN + ratio stage); RANSAC hypotheses/s in `ransac`",
+        "metric": "descriptor-pair distances/s (BF-%s 2-NN + ratio stage); RANSAC hypotheses/s in `ransac`"
+                  % ("Hamming" if hamming else "L2"),
         "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u32 xor/popcount" if hamming else "f32 in/out; coarse pass f16xf16->f32 MFMA (exact for u8-valued data), refinement f32",
+        "dtype": "u8 bits; coarse pass i8xi8->i32 MFMA on +-1 expanded bits (exact), refinement u32 xor/popcount" if hamming else "f32 in/out; coarse pass f16xf16->f32 MFMA (exact for u8-valued data), refinement f32",
         "data": "synthetic",
         "config": {"workload": "%s: %dx%d %s BF-%s 2-NN + ratio 0.8 + %d-hypothesis RANSAC-F (8-point, "
                                "Sampson, tau=1px) per image pair; N>1: query rows and hypothesis ids sharded"
@@ -264,7 +265,18 @@ def main():
     }
     # roofline of the dominant kernel (algorithmic 2*D flop per descriptor pair)
     flops = 2.0 * dim * nq * nt
-    if hamming and "knn_hamming" in kern:
+    if hamming and "knn_hamming_mfma_i8" in kern:
+        # +-1 byte expansion: dot = 256 - 2*hamming, 2*256 integer ops per pair on v_mfma_i32_32x32x32_i8
+        # (dense I8 peak = 2x the BF16 peak: same cycles at twice the K, MI355X_MICROARCH.md MFMA table)
+        ops = 2.0 * 8 * dim * nq * nt
+        ach = ops / (kern["knn_hamming_mfma_i8"] * 1e-6) / 1e12
+        out["roofline"] = {"kernel": "knn_hamming_mfma_i8 (knn_mfma_rows288<RouteI8>)", "bound": "mfma", "achieved": ach,
+                           "peak": 2 * PEAK_F16_MFMA_TFLOPS, "unit": "TOP/s", "frac": ach / (2 * PEAK_F16_MFMA_TFLOPS),
+                           "traffic": None,
+                           "dtype": "i8 (+-1 expanded bits) x i8 -> i32 MFMA; exact",
+                           "note": "the kernel issues 9 k-chunks per 8 data chunks (pad-row seed): 12.5% of the "
+                                   "issued MFMAs are not algorithmic work"}
+    elif hamming and "knn_hamming" in kern:
         # 16 integer VALU ops per pair (8 x v_xor_b32 + 8 x v_bcnt_u32_b32 at 32 B); one wave64 VALU
         # instruction occupies its SIMD 4 cycles: 1024 SIMDs * 64 lanes * 2.4 GHz / 4 = 3.93e13 lane-ops/s
         ops = 16.0 * nq * nt
@@ -277,7 +289,8 @@ def main():
         out["roofline"] = {"kernel": "knn_l2_mfma_f16", "bound": "mfma", "achieved": ach, "peak": PEAK_F16_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": ach / PEAK_F16_MFMA_TFLOPS, "traffic": None,
                            "dtype": "f16-input MFMA, f32 accumulate (v_mfma_f32_32x32x16_f16), exact for u8-valued data",
-                           "note": "selection-bound: 5 VALU ops per pair vs 8 MFMAs per 1024 pairs; see DESIGN.md"}
+                           "note": "VALU-issue bound: the grouped top-4 selection costs 1.75 VALU ops per pair next to "
+                                   "9 MFMAs per 1024 pairs; see DESIGN.md"}
     elif "knn_l2_mfma" in kern:
         ach = flops / (kern["knn_l2_mfma"] * 1e-6) / 1e12
         out["roofline"] = {"kernel": "knn_l2_mfma", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,

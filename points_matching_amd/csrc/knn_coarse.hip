@@ -283,68 +283,107 @@ __global__ __launch_bounds__(256, (TT == 64 ? 2 : 1)) void knn_l2_mfma(
 // MFMAs), walks the 128-row tile one 32-row block at a time and selects block b-1 between the
 // MFMAs of block b, with two alternating accumulator sets.
 // ---------------------------------------------------------------------------------------------
+// The kernel is shared by two routes with the same byte geometry (288-B rows = 9 k-chunks of 32 B,
+// 16 B per lane and MFMA):
+//   RouteF16  v_mfma_f32_32x32x16_f16, values float, group id in the low mantissa bits;
+//   RouteI8   v_mfma_i32_32x32x32_i8 on +-1 bytes (binary descriptors: dot = bits - 2*hamming),
+//             values int, candidate = (dot << I8_SHIFT) | group id.
+// `par` is the f16 route's keep mask (unused by the i8 route: its shift is a constant).
+struct RouteF16 {
+    typedef f16x8 frag;
+    typedef f32x16 acc;
+    typedef f32x4 list;
+    static __device__ __forceinline__ acc zero()
+    {
+        return acc{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    }
+    static __device__ __forceinline__ acc mfma(frag a, frag b, acc c)
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ list empty() { return list{-KNN_BIG, -KNN_BIG, -KNN_BIG, -KNN_BIG}; }
+    static __device__ __forceinline__ void select(const acc& a, unsigned par, unsigned gid, list& cl, int g)
+    {
+        top4_insert(cl, embed_lid(group_max(a, g), par, gid));
+    }
+};
+
+struct RouteI8 {
+    typedef i32x4 frag;
+    typedef i32x16 acc;
+    typedef i32x4 list;
+    static __device__ __forceinline__ acc zero() { return acc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; }
+    static __device__ __forceinline__ acc mfma(frag a, frag b, acc c)
+    {
+        return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ list empty() { return list{I8_EMPTY, I8_EMPTY, I8_EMPTY, I8_EMPTY}; }
+    static __device__ __forceinline__ int med3(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }
+    static __device__ __forceinline__ void select(const acc& a, unsigned par, unsigned gid, list& cl, int g)
+    {
+        const int m = max(max(max(a[4 * g], a[4 * g + 1]), a[4 * g + 2]), a[4 * g + 3]);
+        const int x = static_cast<int>((static_cast<unsigned>(m) << I8_SHIFT) | gid);   // v_lshl_or_b32
+        (void)par;
+        const int n0 = max(x, cl[0]);
+        const int n1 = med3(x, cl[0], cl[1]);
+        const int n2 = med3(x, cl[1], cl[2]);
+        const int n3 = med3(x, cl[2], cl[3]);
+        cl[0] = n0; cl[1] = n1; cl[2] = n2; cl[3] = n3;
+    }
+};
+
 // a tile = 128 rows x 288 B = 2304 x 16 B, staged through registers by THREADS threads
 template <int THREADS>
 struct HTile {
-    static constexpr int TOTAL = H_TT * (H_ROW / 8);
+    static constexpr int TOTAL = H_TT * H_ROW16;
     static constexpr int PIECES = (TOTAL + THREADS - 1) / THREADS;
     static constexpr bool EVEN = TOTAL % THREADS == 0;
     uint4 stg[PIECES];
-    __device__ __forceinline__ void load(const _Float16* __restrict__ Th, int tile, int tid)
+    __device__ __forceinline__ void load(const uint4* __restrict__ Th, int tile, int tid)
     {
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
             int f = tid + THREADS * i;
             if (!EVEN) f = f < TOTAL ? f : TOTAL - 1;          // clamped: the load stays unconditional
-            const int row = f / (H_ROW / 8), c8 = f % (H_ROW / 8);
-            stg[i] = *reinterpret_cast<const uint4*>(Th + static_cast<size_t>(tile * H_TT + row) * H_ROW + 8 * c8);
+            stg[i] = Th[static_cast<size_t>(tile) * TOTAL + f];  // rows are contiguous: piece f of the tile
         }
     }
-    __device__ __forceinline__ void store(_Float16* __restrict__ hsm, int buf, int tid) const
+    __device__ __forceinline__ void store(uint4* __restrict__ hsm, int buf, int tid) const
     {
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
             const int f = tid + THREADS * i;
-            const int row = f / (H_ROW / 8), c8 = f % (H_ROW / 8);
-            if (EVEN || f < TOTAL) *reinterpret_cast<uint4*>(hsm + (buf * H_TT + row) * H_LDS_ROW + 8 * c8) = stg[i];
+            const int row = f / H_ROW16, c8 = f % H_ROW16;
+            if (EVEN || f < TOTAL) hsm[(buf * H_TT + row) * H_LDS_ROW16 + c8] = stg[i];
         }
     }
 };
 
-// keep the 4 largest row groups of this lane's stream for one of its query columns
-__device__ __forceinline__ void h_select(const f32x16& acc, unsigned keep_mask, unsigned gidbase, f32x4& cl, int g0,
-                                         int g1)
-{
-#pragma unroll
-    for (int g = g0; g < g1; ++g)
-        top4_insert(cl, embed_lid(group_max(acc, g), keep_mask, gidbase + static_cast<unsigned>(g)));
-}
-
 // one 32-row block of the tile: 9 k-chunks x NQB query blocks of MFMAs, selecting the previous
-// block's accumulators p[] (group-id base pbase) in between, from chunk 1 on (see knn_tile_compute)
-template <int NQB, bool EPI>
-__device__ __forceinline__ void h_block(const _Float16* __restrict__ tb, const f16x8 (&qf)[NQB][H_NCH],
-                                        f32x16 (&a)[NQB], const f32x16 (&p)[NQB], unsigned pbase,
-                                        unsigned keep_mask, f32x4 (&cl)[NQB])
+// block's accumulators p[] (group-id base pbase) in between, from chunk 1 on (see knn_tile_compute).
+// tb: this lane's row in the LDS tile, in 16-byte units (chunk c = tb[2*c])
+template <typename R, int NQB, bool EPI>
+__device__ __forceinline__ void h_block(const uint4* __restrict__ tb, const typename R::frag (&qf)[NQB][H_NCH],
+                                        typename R::acc (&a)[NQB], const typename R::acc (&p)[NQB], unsigned pbase,
+                                        unsigned par, typename R::list (&cl)[NQB])
 {
-    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    typedef typename R::frag frag;
     // A fragments run three chunks ahead of their use: one chunk is only 32*NQB pipe cycles, less
     // than an LDS round trip
-    f16x8 ring[3];
+    frag ring[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) ring[c] = *reinterpret_cast<const f16x8*>(tb + 16 * c);
+    for (int c = 0; c < 3; ++c) ring[c] = *reinterpret_cast<const frag*>(tb + 2 * c);
 #pragma unroll
     for (int c = 0; c < H_NCH; ++c) {
-        const f16x8 x = ring[c % 3];
-        if (c + 3 < H_NCH) ring[c % 3] = *reinterpret_cast<const f16x8*>(tb + 16 * (c + 3));
+        const frag x = ring[c % 3];
+        if (c + 3 < H_NCH) ring[c % 3] = *reinterpret_cast<const frag*>(tb + 2 * (c + 3));
 #pragma unroll
-        for (int qb = 0; qb < NQB; ++qb)
-            a[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, qf[qb][c], c == 0 ? zero : a[qb], 0, 0, 0);
+        for (int qb = 0; qb < NQB; ++qb) a[qb] = R::mfma(x, qf[qb][c], c == 0 ? R::zero() : a[qb]);
         if (EPI && c >= 1) {                      // 4*NQB row groups over chunks 1..8
             constexpr int NGB = 4 * NQB;
 #pragma unroll
             for (int e = (c - 1) * NGB / 8; e < c * NGB / 8; ++e)       // query column e % NQB, group e / NQB
-                h_select(p[e % NQB], keep_mask, pbase, cl[e % NQB], e / NQB, e / NQB + 1);
+                R::select(p[e % NQB], par, pbase + static_cast<unsigned>(e / NQB), cl[e % NQB], e / NQB);
             if (NQB == 2)
                 asm volatile("" : "+v"(cl[0][0]), "+v"(cl[0][1]), "+v"(cl[0][2]), "+v"(cl[0][3]), "+v"(cl[NQB - 1][0]),
                              "+v"(cl[NQB - 1][1]), "+v"(cl[NQB - 1][2]), "+v"(cl[NQB - 1][3]));
@@ -357,29 +396,32 @@ __device__ __forceinline__ void h_block(const _Float16* __restrict__ tb, const f
 // NQB query blocks (of 32) per wave: 2 -> 4 waves per workgroup, 2 waves per SIMD (each A fragment
 // feeds two MFMAs); 1 -> 8 waves per workgroup, 4 waves per SIMD at <= 128 VGPRs (more waves to
 // cover LDS / barrier / MFMA-dependency latency).  Either way a workgroup owns H_QB = 256 queries.
-// mode: 0 = run always (hint), 1 = run only if prep16 found the data eligible (auto)
-template <int NQB>
-__global__ __launch_bounds__(H_QB / (32 * NQB) * 64, (NQB == 2 ? 2 : 4)) void knn_l2_mfma_f16(
-    const _Float16* __restrict__ Qh, const _Float16* __restrict__ Th, int nq, int nt, int tiles_per_split,
-    unsigned keep_mask, float* __restrict__ cand_val, int slots, const unsigned long long* __restrict__ stats,
-    unsigned epoch, int mode)
+// mode: 0 = run always (hint / i8), 1 = run only if prep16 found the data eligible (auto)
+template <typename R, int NQB>
+__global__ __launch_bounds__(H_QB / (32 * NQB) * 64, (NQB == 2 ? 2 : 4)) void knn_mfma_rows288(
+    const uint4* __restrict__ Qh, const uint4* __restrict__ Th, int nq, int nt, int tiles_per_split, unsigned par,
+    typename R::list* __restrict__ cand_val, int slots, const unsigned long long* __restrict__ stats, unsigned epoch,
+    int mode)
 {
+    typedef typename R::frag frag;
+    typedef typename R::acc acc;
+    typedef typename R::list list;
     constexpr int THREADS = H_QB / (32 * NQB) * 64;
     if (mode == 1) {
         const unsigned long long s1 = stats[1];
         if (static_cast<unsigned>(s1 >> 32) == epoch && (s1 & 2ull)) return;      // f32 route takes over
     }
-    extern __shared__ __attribute__((aligned(16))) _Float16 hsm[];                // [2][H_TT][H_LDS_ROW]
+    extern __shared__ __attribute__((aligned(16))) uint4 hsm[];                   // [2][H_TT][H_LDS_ROW16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int qbase = blockIdx.x * H_QB + wave * 32 * NQB;
 
-    f16x8 qf[NQB][H_NCH];
+    frag qf[NQB][H_NCH];
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
         for (int c = 0; c < H_NCH; ++c)
-            qf[qb][c] = *reinterpret_cast<const f16x8*>(Qh + static_cast<size_t>(qbase + 32 * qb + r) * H_ROW + 16 * c + 8 * h);
+            qf[qb][c] = *reinterpret_cast<const frag*>(Qh + static_cast<size_t>(qbase + 32 * qb + r) * H_ROW16 + 2 * c + h);
     // make the fragments opaque: hipcc otherwise treats the loads as rematerialisable and re-reads
     // some of them from global memory inside the tile loop
 #pragma unroll
@@ -389,16 +431,16 @@ __global__ __launch_bounds__(H_QB / (32 * NQB) * 64, (NQB == 2 ? 2 : 4)) void kn
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             u32x4 t = __builtin_bit_cast(u32x4, qf[qb][c]);
             asm volatile("" : "+v"(t));
-            qf[qb][c] = __builtin_bit_cast(f16x8, t);
+            qf[qb][c] = __builtin_bit_cast(frag, t);
         }
 
     const int ntiles = (nt + H_TT - 1) / H_TT;
     const int tile0 = blockIdx.y * tiles_per_split;
     int tile1 = tile0 + tiles_per_split;
     if (tile1 > ntiles) tile1 = ntiles;
-    f32x4 cl[NQB];
+    list cl[NQB];
 #pragma unroll
-    for (int qb = 0; qb < NQB; ++qb) cl[qb] = f32x4{-KNN_BIG, -KNN_BIG, -KNN_BIG, -KNN_BIG};
+    for (int qb = 0; qb < NQB; ++qb) cl[qb] = R::empty();
 
     HTile<THREADS> st;
 
@@ -406,29 +448,31 @@ __global__ __launch_bounds__(H_QB / (32 * NQB) * 64, (NQB == 2 ? 2 : 4)) void kn
         st.load(Th, tile0, tid);
         st.store(hsm, 0, tid);
         __syncthreads();
-        f32x16 A[NQB], B[NQB];
+        acc A[NQB], B[NQB];
         for (int tix = 0; tix < tile1 - tile0; ++tix) {
             const int buf = tix & 1;
-            const _Float16* tb = hsm + (buf * H_TT + r) * H_LDS_ROW + 8 * h;
+            const uint4* tb = hsm + (buf * H_TT + r) * H_LDS_ROW16 + h;
             const unsigned lb = static_cast<unsigned>(tix) * 16u;          // group ids of this tile: lb + 4*blk + g
             // the last tile is simply staged again: past the end nothing reads the other buffer
             st.load(Th, tile0 + tix + 1 < ntiles ? tile0 + tix + 1 : tile0 + tix, tid);
-            if (tix == 0) h_block<NQB, false>(tb, qf, A, A, 0u, keep_mask, cl);
-            else h_block<NQB, true>(tb, qf, A, B, lb - 4u, keep_mask, cl);                        // B = block 3 of tile-1
-            h_block<NQB, true>(tb + 32 * H_LDS_ROW, qf, B, A, lb, keep_mask, cl);
-            h_block<NQB, true>(tb + 64 * H_LDS_ROW, qf, A, B, lb + 4u, keep_mask, cl);
+            if (tix == 0) h_block<R, NQB, false>(tb, qf, A, A, 0u, par, cl);
+            else h_block<R, NQB, true>(tb, qf, A, B, lb - 4u, par, cl);                        // B = block 3 of tile-1
+            h_block<R, NQB, true>(tb + 32 * H_LDS_ROW16, qf, B, A, lb, par, cl);
+            h_block<R, NQB, true>(tb + 64 * H_LDS_ROW16, qf, A, B, lb + 4u, par, cl);
             st.store(hsm, buf ^ 1, tid);
-            h_block<NQB, true>(tb + 96 * H_LDS_ROW, qf, B, A, lb + 8u, keep_mask, cl);
+            h_block<R, NQB, true>(tb + 96 * H_LDS_ROW16, qf, B, A, lb + 8u, par, cl);
             __syncthreads();
         }
         const unsigned lb = static_cast<unsigned>(tile1 - tile0 - 1) * 16u + 12u;
 #pragma unroll
-        for (int qb = 0; qb < NQB; ++qb) h_select(B[qb], keep_mask, lb, cl[qb], 0, 4);
+        for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) R::select(B[qb], par, lb + static_cast<unsigned>(g), cl[qb], g);
     }
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
         const int q = qbase + 32 * qb + r;
-        if (q < nq) *reinterpret_cast<f32x4*>(cand_val + static_cast<size_t>(q) * slots + (blockIdx.y * 2 + h) * KNN_C) = cl[qb];
+        if (q < nq) cand_val[(static_cast<size_t>(q) * slots + (blockIdx.y * 2 + h) * KNN_C) / KNN_C] = cl[qb];
     }
 }
 
@@ -471,31 +515,50 @@ int launch_coarse_f32(pm_ctx* ctx, const float* dq, int nq, const float* dt, int
 #undef PM_LAUNCH_MFMA
 }
 
-int launch_coarse_f16(pm_ctx* ctx, const _Float16* Qh, const _Float16* Th, int nq, int nq_pad, int nt, int splits,
-                      int tiles_per_split, unsigned keep_mask, float* cval, int slots,
-                      const unsigned long long* stats, unsigned epoch, int mode)
+template <typename R>
+int launch_rows288(pm_ctx* ctx, const char* name, const void* Qh, const void* Th, int nq, int nq_pad, int nt, int splits,
+                   int tiles_per_split, unsigned par, void* cval, int slots, const unsigned long long* stats,
+                   unsigned epoch, int mode)
 {
-    const size_t lds = sizeof(_Float16) * 2 * H_TT * H_LDS_ROW;
+    const size_t lds = sizeof(uint4) * 2 * H_TT * H_LDS_ROW16;
     static const int nqb_env = [] { const char* e = getenv("PM_KNN_F16_NQB"); return e ? atoi(e) : 0; }();
     // few tiles per workgroup: the 8-wave form covers latency better; long sweeps: the 4-wave form halves LDS reads
     const int nqb = nqb_env == 1 || nqb_env == 2 ? nqb_env : (tiles_per_split <= 8 ? 1 : 2);
     static bool attr_done = false;
     if (!attr_done) {
-        PM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_l2_mfma_f16<1>),
+        PM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_mfma_rows288<R, 1>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-        PM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_l2_mfma_f16<2>),
+        PM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_mfma_rows288<R, 2>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
         attr_done = true;
     }
-    pm::ScopedKernelTime t(ctx, "knn_l2_mfma_f16");
+    pm::ScopedKernelTime t(ctx, name);
+    const uint4* q4 = static_cast<const uint4*>(Qh);
+    const uint4* t4 = static_cast<const uint4*>(Th);
+    typename R::list* out = static_cast<typename R::list*>(cval);
     if (nqb == 2)
-        hipLaunchKernelGGL(knn_l2_mfma_f16<2>, dim3(nq_pad / H_QB, splits), dim3(256), lds, ctx->stream, Qh, Th, nq, nt,
-                           tiles_per_split, keep_mask, cval, slots, stats, epoch, mode);
+        hipLaunchKernelGGL((knn_mfma_rows288<R, 2>), dim3(nq_pad / H_QB, splits), dim3(256), lds, ctx->stream, q4, t4, nq,
+                           nt, tiles_per_split, par, out, slots, stats, epoch, mode);
     else
-        hipLaunchKernelGGL(knn_l2_mfma_f16<1>, dim3(nq_pad / H_QB, splits), dim3(512), lds, ctx->stream, Qh, Th, nq, nt,
-                           tiles_per_split, keep_mask, cval, slots, stats, epoch, mode);
+        hipLaunchKernelGGL((knn_mfma_rows288<R, 1>), dim3(nq_pad / H_QB, splits), dim3(512), lds, ctx->stream, q4, t4, nq,
+                           nt, tiles_per_split, par, out, slots, stats, epoch, mode);
     PM_HIP_CHECK(hipGetLastError());
     return PM_OK;
+}
+
+int launch_coarse_f16(pm_ctx* ctx, const _Float16* Qh, const _Float16* Th, int nq, int nq_pad, int nt, int splits,
+                      int tiles_per_split, unsigned keep_mask, float* cval, int slots,
+                      const unsigned long long* stats, unsigned epoch, int mode)
+{
+    return launch_rows288<RouteF16>(ctx, "knn_l2_mfma_f16", Qh, Th, nq, nq_pad, nt, splits, tiles_per_split, keep_mask,
+                                    cval, slots, stats, epoch, mode);
+}
+
+int launch_coarse_i8(pm_ctx* ctx, const void* Qe, const void* Te, int nq, int nq_pad, int nt, int splits,
+                     int tiles_per_split, int* cval, int slots)
+{
+    return launch_rows288<RouteI8>(ctx, "knn_hamming_mfma_i8", Qe, Te, nq, nq_pad, nt, splits, tiles_per_split, 0u,
+                                   cval, slots, nullptr, 0u, 0);
 }
 
 }  // namespace pm_knn

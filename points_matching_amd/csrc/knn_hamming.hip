@@ -8,9 +8,21 @@
 // over gridDim.y; each lane keeps its KL best (distance, index) pairs in registers and a small
 // merge kernel combines the splits.  k > 4 runs ceil(k/4) passes, each admitting only pairs
 // above the last pair the previous pass emitted.
-#include "pm_common.hpp"
+//
+// 256-bit descriptors with k <= 2 (ORB + ratio test: config C4) take the matrix-core route
+// instead: the bits are expanded to +-1 bytes, so that v_mfma_i32_32x32x32_i8 yields
+// dot = 256 - 2*hamming for 32x32 pairs per instruction (16x the VALU rate); the coarse kernel is
+// knn_coarse.hip's 288-byte-row kernel (shared with the f16 L2 route) keeping, per lane stream,
+// the 4 best 4-row groups, and knn_hamming_refine re-evaluates the candidate rows with popcounts.
+// The integers are exact on both sides, so the window logic has no epsilon: a row can only be
+// missed if its sub-list overflowed, which the 4th entry reveals (then that sub-list's rows are
+// scanned).
+#include <cstdlib>
+
+#include "knn_shared.hpp"
 
 namespace {
+using namespace pm_knn;
 
 constexpr float HM_INF = __builtin_inff();
 constexpr int HM_BIG = 0x7FFFFFFF;
@@ -175,6 +187,211 @@ int run_passes(pm_ctx* ctx, const uint32_t* dq, int nq, const uint32_t* dt, int 
     return PM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// i8 route
+// ---------------------------------------------------------------------------------------------
+// 4 descriptor bits -> 4 bytes: 0x01 where the bit is set, 0xFF (-1) where it is clear
+__device__ __forceinline__ uint32_t expand_nibble(uint32_t nib)
+{
+    const uint32_t ones = (nib * 0x00204081u) & 0x01010101u;
+    return 0xFFFFFFFFu ^ (ones * 0xFEu);
+}
+
+// one thread per (row, 32-byte chunk): chunks 0..7 = the 8 descriptor words, chunk 8 = seed chunk.
+// Rows >= n of the padded copy are all-zero data; a padded TRAIN row carries -128 in the seed byte,
+// every QUERY row carries 127 there: the pad rows' dot is -16256, below any real row's (>= -256).
+__global__ __launch_bounds__(256) void knn_hamming_expand(const uint32_t* __restrict__ Q, int nq, int nq_pad,
+                                                          const uint32_t* __restrict__ T, int nt, int nt_pad,
+                                                          uint4* __restrict__ Qe, uint4* __restrict__ Te)
+{
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int total_q = nq_pad * H_NCH;
+    const bool is_q = gid < total_q;
+    const int e = is_q ? gid : gid - total_q;
+    if (!is_q && e >= nt_pad * H_NCH) return;
+    const int row = e / H_NCH, c = e % H_NCH;
+    const int n = is_q ? nq : nt;
+    uint4 lo = uint4{0u, 0u, 0u, 0u}, hi = uint4{0u, 0u, 0u, 0u};
+    if (c < 8) {
+        if (row < n) {
+            const uint32_t w = (is_q ? Q : T)[static_cast<size_t>(row) * 8 + c];
+            lo = uint4{expand_nibble(w & 15u), expand_nibble((w >> 4) & 15u), expand_nibble((w >> 8) & 15u),
+                       expand_nibble((w >> 12) & 15u)};
+            hi = uint4{expand_nibble((w >> 16) & 15u), expand_nibble((w >> 20) & 15u), expand_nibble((w >> 24) & 15u),
+                       expand_nibble(w >> 28)};
+        }
+    } else {
+        if (is_q) lo.x = 127u;
+        else if (row >= n) lo.x = 0x80u;
+    }
+    uint4* dst = (is_q ? Qe : Te) + static_cast<size_t>(row) * H_ROW16 + 2 * c;
+    dst[0] = lo;
+    dst[1] = hi;
+}
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned long long w = __shfl_xor(v, o, 64);
+        v = w < v ? w : v;
+    }
+    return v;
+}
+
+struct Best2 {
+    unsigned long long a, b;       // a <= b
+    __device__ __forceinline__ void insert(unsigned long long key)
+    {
+        if (key < a) { b = a; a = key; }
+        else if (key < b) b = key;
+    }
+};
+
+__device__ __forceinline__ unsigned long long hamming_key256(const uint4 q0, const uint4 q1,
+                                                             const uint32_t* __restrict__ T, int row)
+{
+    const uint4* tr = reinterpret_cast<const uint4*>(T + static_cast<size_t>(row) * 8);
+    const uint4 t0 = tr[0], t1 = tr[1];
+    const int d = __builtin_popcount(q0.x ^ t0.x) + __builtin_popcount(q0.y ^ t0.y) + __builtin_popcount(q0.z ^ t0.z) +
+                  __builtin_popcount(q0.w ^ t0.w) + __builtin_popcount(q1.x ^ t1.x) + __builtin_popcount(q1.y ^ t1.y) +
+                  __builtin_popcount(q1.z ^ t1.z) + __builtin_popcount(q1.w ^ t1.w);
+    return (static_cast<unsigned long long>(d) << 32) | static_cast<unsigned>(row);
+}
+
+// One wave per query.  cand: [nq][slots] ints, sub-list s = entries 4s..4s+3 in descending order,
+// s = split*2 + lane half; entry = (dot << shift) | gid, gid = tile_in_split*16 + block*4 + group.
+constexpr int HR_MAXE = 8;          // entries per lane: slots <= 512
+__global__ __launch_bounds__(256) void knn_hamming_refine(const uint32_t* __restrict__ Q, const uint32_t* __restrict__ T,
+                                                          int nq, int nt, int k, const int* __restrict__ cand,
+                                                          int slots, int tiles_per_split, int shift,
+                                                          pm_match* __restrict__ out)
+{
+    __shared__ int clist[4][64 * HR_MAXE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wave;
+    if (q >= nq) return;                                     // wave-uniform; no block barriers below
+    const uint4* qr = reinterpret_cast<const uint4*>(Q + static_cast<size_t>(q) * 8);
+    const uint4 q0 = qr[0], q1 = qr[1];
+    const int gmask = (1 << shift) - 1;
+
+    int v[HR_MAXE], dc[HR_MAXE];
+#pragma unroll
+    for (int i = 0; i < HR_MAXE; ++i) {
+        const int e = lane + 64 * i;
+        v[i] = e < slots ? cand[static_cast<size_t>(q) * slots + e] : I8_EMPTY;
+        dc[i] = v[i] == I8_EMPTY ? 0x7FFFFFF0 : ((I8_BITS - (v[i] >> shift)) >> 1);      // coarse (= exact) distance
+    }
+    // tau = k-th smallest entry distance (entries are distinct groups, so k distinct rows lie within tau)
+    unsigned long long lastk = 0ull;
+    int tau = 0;
+    for (int c = 0; c < k; ++c) {
+        unsigned long long m = ~0ull;
+#pragma unroll
+        for (int i = 0; i < HR_MAXE; ++i) {
+            const unsigned long long key = (static_cast<unsigned long long>(static_cast<unsigned>(dc[i])) << 32) |
+                                           static_cast<unsigned>(lane + 64 * i);
+            if ((c == 0 || key > lastk) && key < m) m = key;
+        }
+        m = wave_min_u64(m);
+        lastk = m;
+        tau = static_cast<int>(m >> 32);
+    }
+    // sub-lists whose 4th entry is within tau may have dropped a row within tau: scan them whole
+    Best2 best{~0ull, ~0ull};
+    int total = 0;
+#pragma unroll
+    for (int i = 0; i < HR_MAXE; ++i) {
+        if (64 * i >= slots) break;                          // wave-uniform
+        const bool within = v[i] != I8_EMPTY && dc[i] <= tau;
+        const unsigned long long full = __ballot(within && (lane & 3) == 3);
+        const bool my_full = (full >> (lane | 3)) & 1ull;
+        const unsigned long long cm = __ballot(within && !my_full);
+        if (within && !my_full) clist[wave][total + __popcll(cm & ((1ull << lane) - 1ull))] = (v[i] & gmask) | (((lane + 64 * i) >> 2) << 16);
+        total += __popcll(cm);
+        unsigned long long f = full;
+        while (f) {                                          // rare
+            const int src = __ffsll(static_cast<long long>(f)) - 1;
+            f &= f - 1ull;
+            const int sub = (src + 64 * i) >> 2, split = sub >> 1, hh = sub & 1;
+            for (int idx = lane; idx < tiles_per_split * 64; idx += 64) {
+                const int tile = idx >> 6, rem = idx & 63;
+                const int row = (split * tiles_per_split + tile) * H_TT + 32 * (rem >> 4) + 8 * ((rem >> 2) & 3) + 4 * hh +
+                                (rem & 3);
+                if (row < nt) best.insert(hamming_key256(q0, q1, T, row));
+            }
+        }
+    }
+    // candidate groups: 4 rows each, one row per lane, 16 groups per round
+    for (int base = 0; base < 4 * total; base += 64) {
+        const int t = base + lane;
+        if (t < 4 * total) {
+            const int ent = clist[wave][t >> 2];
+            const int gid = ent & 0xFFFF, sub = ent >> 16, split = sub >> 1, hh = sub & 1;
+            const int tile = gid >> 4, rem = gid & 15;
+            const int row = (split * tiles_per_split + tile) * H_TT + 32 * (rem >> 2) + 8 * (rem & 3) + 4 * hh + (t & 3);
+            if (row < nt) best.insert(hamming_key256(q0, q1, T, row));
+        }
+    }
+    for (int c = 0; c < k; ++c) {
+        const unsigned long long m = wave_min_u64(best.a);
+        if (best.a == m && m != ~0ull) { best.a = best.b; best.b = ~0ull; }      // keys are unique rows
+        if (lane == 0) {
+            pm_match mm;
+            mm.queryIdx = q;
+            mm.imgIdx = 0;
+            if (m == ~0ull) { mm.trainIdx = -1; mm.distance = HM_INF; }
+            else { mm.trainIdx = static_cast<int>(m & 0xFFFFFFFFull); mm.distance = static_cast<float>(static_cast<int>(m >> 32)); }
+            out[static_cast<size_t>(q) * k + c] = mm;
+        }
+    }
+}
+
+// 256-bit descriptors, k <= 2
+int run_mfma(pm_ctx* ctx, const uint32_t* dq, int nq, const uint32_t* dt, int nt, int k, pm_match* dout, bool* done)
+{
+    *done = false;
+    const int nq_pad = (nq + H_QB - 1) / H_QB * H_QB, nt_pad = (nt + H_TT - 1) / H_TT * H_TT;
+    const int nqb = nq_pad / H_QB, ntiles = nt_pad / H_TT;
+    int splits = (2 * ctx->n_cu + nqb - 1) / nqb;
+    if (splits > ntiles) splits = ntiles;
+    if (splits > 64) splits = 64;
+    if (splits < 1) splits = 1;
+    const int tiles_per_split = (ntiles + splits - 1) / splits;
+    splits = (ntiles + tiles_per_split - 1) / tiles_per_split;
+    const int slots = splits * 2 * KNN_C;
+    constexpr int shift = I8_SHIFT;
+    if (tiles_per_split * (H_TT / 8) > (1 << shift)) return PM_OK;      // > 64k groups per lane stream: VALU route
+
+    const size_t cb = sizeof(int) * static_cast<size_t>(nq) * slots;
+    const size_t qe = sizeof(uint4) * static_cast<size_t>(nq_pad) * H_ROW16, te = sizeof(uint4) * static_cast<size_t>(nt_pad) * H_ROW16;
+    const size_t need = pm::align_up(cb, 256) + pm::align_up(qe, 256) + pm::align_up(te, 256) + 1024;
+    int rc = pm::arena_reserve(ctx, need);
+    if (rc != PM_OK) return rc;
+    pm::arena_reset(ctx);
+    int* cval = static_cast<int*>(pm::arena_take(ctx, cb));
+    uint4* Qe = static_cast<uint4*>(pm::arena_take(ctx, qe));
+    uint4* Te = static_cast<uint4*>(pm::arena_take(ctx, te));
+    PM_REQUIRE(cval && Qe && Te, PM_E_NOMEM, "scratch arena too small");
+    {
+        pm::ScopedKernelTime t(ctx, "knn_hamming_expand");
+        const int total = (nq_pad + nt_pad) * H_NCH;
+        hipLaunchKernelGGL(knn_hamming_expand, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, dq, nq, nq_pad, dt, nt,
+                           nt_pad, Qe, Te);
+        PM_HIP_CHECK(hipGetLastError());
+    }
+    rc = launch_coarse_i8(ctx, Qe, Te, nq, nq_pad, nt, splits, tiles_per_split, cval, slots);
+    if (rc != PM_OK) return rc;
+    {
+        pm::ScopedKernelTime t(ctx, "knn_hamming_refine");
+        hipLaunchKernelGGL(knn_hamming_refine, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, dq, dt, nq, nt, k, cval, slots,
+                           tiles_per_split, shift, dout);
+        PM_HIP_CHECK(hipGetLastError());
+    }
+    *done = true;
+    return PM_OK;
+}
+
 }  // namespace
 
 extern "C" int pm_bf_knn_hamming_u8_dev(pm_ctx* ctx, const uint8_t* dq, int nq, const uint8_t* dt, int nt,
@@ -192,6 +409,14 @@ extern "C" int pm_bf_knn_hamming_u8_dev(pm_ctx* ctx, const uint8_t* dq, int nq, 
     const uint32_t* q32 = reinterpret_cast<const uint32_t*>(dq);
     const uint32_t* t32 = reinterpret_cast<const uint32_t*>(dt);
     const int nw = bytes / 4;
+    const char* route_env = getenv("PM_HAMMING_ROUTE");          // "valu" pins the VALU scan (tests, A/B timing)
+    const bool force_valu = route_env && route_env[0] == 'v';
+    if (bytes * 8 == I8_BITS && k <= 2 && nt >= 1 && !force_valu &&
+        (reinterpret_cast<uintptr_t>(dq) & 15) == 0 && (reinterpret_cast<uintptr_t>(dt) & 15) == 0) {
+        bool done = false;
+        const int rc = run_mfma(ctx, q32, nq, t32, nt, k, dout, &done);
+        if (rc != PM_OK || done) return rc;
+    }
     if (k == 1) return run_passes<1>(ctx, q32, nq, t32, nt, nw, k, dout);
     if (k == 2) return run_passes<2>(ctx, q32, nq, t32, nt, nw, k, dout);
     return run_passes<4>(ctx, q32, nq, t32, nt, nw, k, dout);

@@ -11,6 +11,8 @@ namespace pm_knn {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int KNN_C = 4;          // coarse candidates kept per (query, split, lane-half)
 constexpr int QB = 128;           // queries per workgroup, f32 route (4 waves x 32)
@@ -25,6 +27,14 @@ constexpr int H_NCH = H_ROW / 16;       // 9 k-chunks of 16
 constexpr int H_TT = 128;               // train rows per tile
 constexpr int H_QB = 256;               // queries per workgroup (4 waves x 64)
 constexpr float H_MAXABS = 361.f;       // 128 * 361^2 < 2^24
+constexpr int H_ROW16 = H_ROW / 8;      // 16-byte units per global row (18)
+constexpr int H_LDS_ROW16 = H_LDS_ROW / 8;   // 16-byte units per LDS row (19)
+
+// i8 route (256-bit binary descriptors expanded to +-1 bytes; same 288-byte row geometry: 8 data
+// chunks of 32 bytes + one seed chunk whose first byte is 127 for queries and -128 for pad rows)
+constexpr int I8_BITS = 256;
+constexpr int I8_SHIFT = 16;             // candidate = (dot << 16) | group id; |dot| <= 16512 fits
+constexpr int I8_EMPTY = static_cast<int>(0x80000000u);   // an unfilled list entry
 
 // Enqueue the f32-MFMA coarse pass (dim % 4 == 0, dim <= 128).  only_if_ineligible != 0: the
 // kernel runs only when prep16 flagged the data as not f16-eligible (auto route).
@@ -35,5 +45,10 @@ int launch_coarse_f32(pm_ctx* ctx, const float* dq, int nq, const float* dt, int
 int launch_coarse_f16(pm_ctx* ctx, const _Float16* Qh, const _Float16* Th, int nq, int nq_pad, int nt, int splits,
                       int tiles_per_split, unsigned keep_mask, float* cval, int slots,
                       const unsigned long long* stats, unsigned epoch, int mode);
+
+// Enqueue the i8-MFMA coarse pass of the Hamming matcher on the expanded +-1 copies.  A candidate
+// is (dot << I8_SHIFT) | group id, dot = 256 - 2*hamming.
+int launch_coarse_i8(pm_ctx* ctx, const void* Qe, const void* Te, int nq, int nq_pad, int nt, int splits,
+                     int tiles_per_split, int* cval, int slots);
 
 }  // namespace pm_knn

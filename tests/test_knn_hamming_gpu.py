@@ -60,3 +60,56 @@ def _requery(m, off):
     m = m.copy()
     m["queryIdx"] += off
     return m
+
+
+# ---- matrix-core (i8) route: 256-bit descriptors, k <= 2 -------------------------------------
+@pytest.mark.parametrize("nq,nt,k", [(700, 1000, 2), (257, 129, 1), (5, 128, 2), (1030, 4100, 2), (64, 2, 2)])
+def test_hamming_i8_route_matches_valu_route_and_oracle(ctx, oracle, nq, nt, k, monkeypatch):
+    q, t, _ = synth.orb_like(nq, nt, 32, seed=7 * nq + nt)
+    got = ctx.bf_knn_hamming(q, t, k)
+    monkeypatch.setenv("PM_HAMMING_ROUTE", "valu")
+    valu = ctx.bf_knn_hamming(q, t, k)
+    monkeypatch.delenv("PM_HAMMING_ROUTE")
+    assert_matches_equal(got, valu, "i8 vs valu")
+    assert_matches_equal(got, oracle.bf_knn_hamming(q, t, k), "i8 vs oracle")
+
+
+def test_hamming_i8_route_is_the_one_timed(ctx):
+    q, t, _ = synth.orb_like(512, 512, 32, seed=5)
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    ctx.bf_knn_hamming(q, t, 2)
+    launches = {n: ctx.timing_get(n)[1] for n in ("knn_hamming_mfma_i8", "knn_hamming_refine", "knn_hamming")}
+    ctx.timing_enable(False)
+    assert launches == {"knn_hamming_mfma_i8": 1, "knn_hamming_refine": 1, "knn_hamming": 0}, launches
+
+
+def test_hamming_i8_degenerate_ties_force_sublist_scans(ctx, oracle):
+    """All-equal and few-valued descriptors: every group ties, every sub-list overflows."""
+    rng = np.random.default_rng(3)
+    t = np.zeros((600, 32), np.uint8)
+    q = np.zeros((70, 32), np.uint8)
+    assert_matches_equal(ctx.bf_knn_hamming(q, t, 2), oracle.bf_knn_hamming(q, t, 2), "all zero")
+    # three distinct rows repeated: many exact ties at the k-th distance
+    base = rng.integers(0, 256, (3, 32), dtype=np.uint8)
+    t = base[rng.integers(0, 3, 900)]
+    q = base[rng.integers(0, 3, 130)]
+    q[::7] ^= 1
+    assert_matches_equal(ctx.bf_knn_hamming(q, t, 2), oracle.bf_knn_hamming(q, t, 2), "three values")
+    # complemented queries: every distance > 128, pad rows (coarse distance 8256) must still lose
+    t = rng.integers(0, 256, (130, 32), dtype=np.uint8)
+    q = (~t[:40]).copy()
+    assert_matches_equal(ctx.bf_knn_hamming(q, t, 2), oracle.bf_knn_hamming(q, t, 2), "complement")
+
+
+def test_hamming_i8_cluster_in_one_group_stream(ctx, oracle):
+    """More than 4 near rows inside one lane stream (same split, same half): the 4-deep list overflows."""
+    rng = np.random.default_rng(11)
+    t = rng.integers(0, 256, (2048, 32), dtype=np.uint8)
+    q = rng.integers(0, 256, (96, 32), dtype=np.uint8)
+    rows = [0, 8, 16, 24, 32, 40, 64, 72]            # rows with (row % 8) < 4: lane half 0, distinct groups
+    for i, r in enumerate(rows):
+        t[r] = q[0]
+        t[r, 31] ^= np.uint8(1 << (i % 8))          # distance 1 each
+    t[1000] = q[0]
+    assert_matches_equal(ctx.bf_knn_hamming(q, t, 2), oracle.bf_knn_hamming(q, t, 2), "cluster")
