@@ -35,6 +35,96 @@ PEAK_F32_VALU_TFLOPS = 157.3
 PEAK_F16_MFMA_TFLOPS = 2500.0    # dense f16/bf16 MFMA (spec; the 5 PF headline includes 2:1 sparsity)
 
 
+def bench_c5(args, world, rank, local_rank, dev, multi, saved_stdout):
+    """BASELINE configs[4]: a batch of 256 independent image pairs x 4096 SIFT-128 descriptors, H = 2048
+    hypotheses per pair, streamed end to end INCLUDING H2D of the descriptors/keypoints and D2H of the
+    results (pm_batch_run: `lanes` streams per GPU).  Pairs are sharded over the ranks (pair p -> rank
+    p mod N, no collective: SURVEY.md 8e).  One step = the whole batch once."""
+    import torch
+    import torch.distributed as dist
+    import points_matching_amd as pm
+    from points_matching_amd import synth
+
+    n, dim, H, ratio, thresh, seed = 4096, 128, 2048, 0.8, 1.0, 0x5EED
+    my_pairs = [p for p in range(args.pairs) if p % world == rank]
+    distinct = min(len(my_pairs), 16)          # distinct synthetic pairs held in pinned memory, cycled
+    hold = []
+    for i in range(distinct):
+        w = synth.pair_workload(n, n, dim, seed=0xC5 + my_pairs[i], kind="sift")
+        hold.append({k: torch.from_numpy(np.ascontiguousarray(w[k])).pin_memory() for k in ("q", "t", "kp1", "kp2")})
+    jobs = []
+    for i in range(len(my_pairs)):
+        h = hold[i % distinct]
+        jobs.append((h["q"].data_ptr(), n, h["t"].data_ptr(), n, h["kp1"].data_ptr(), h["kp2"].data_ptr()))
+    batch = pm.api.PairBatch(local_rank, args.lanes, n, n, dim)
+    arr = batch.make_jobs(jobs)
+    flags = pm.api.PM_KNN_HINT_INTEGER
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    res = None
+    for _ in range(max(1, args.warmup // 5)):
+        res, _, _ = batch.run(arr, ratio, H, thresh, seed, knn_flags=flags)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res, _, _ = batch.run(arr, ratio, H, thresh, seed, knn_flags=flags)
+    fence()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt.item())
+
+    parity = "skipped"
+    if not args.no_verify and rank == 0:
+        from oracle import pm_oracle as O
+        ok = True
+        for j in (0, min(1, len(my_pairs) - 1)):
+            w = synth.pair_workload(n, n, dim, seed=0xC5 + my_pairs[j % distinct], kind="sift")
+            knn = O.bf_knn_l2(w["q"], w["t"], 2, nthreads=8)
+            good = O.filter_ratio(knn, ratio)
+            rc, F_o, mask_o, ninl_o, key_o = O.ransac_fundamental(w["kp1"][good["queryIdx"]], w["kp2"][good["trainIdx"]],
+                                                                  H, thresh, seed, nthreads=8)
+            r = res[j]
+            ok = ok and r.n_good == good.size and r.best_key == key_o and r.n_inliers == ninl_o and \
+                (np.array(r.F[:]).view(np.uint64) == F_o.reshape(9).view(np.uint64)).all()
+        parity = "ok" if ok else "MISMATCH"
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    P = args.pairs
+    ms_per_step = wall / args.steps * 1e3
+    pairs_per_s = P / (ms_per_step * 1e-3)
+    h2d = (2 * n * dim * 4 + 2 * n * 8)
+    out = {
+        "metric": "descriptor-pair distances/s (BF-L2 2-NN + ratio stage); RANSAC hypotheses/s in `ransac`",
+        "value": pairs_per_s * n * n, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32 in/out; coarse pass f16xf16->f32 MFMA (exact for u8-valued data), refinement f32",
+        "data": "synthetic",
+        "config": {"workload": "C5: batch of %d image pairs x (%d x %d SIFT-128 f32 BF-L2 2-NN + ratio 0.8 + %d-hypothesis "
+                               "RANSAC-F), end to end incl. H2D/D2H from pinned host memory, %d lanes per GPU; pairs "
+                               "sharded over ranks, no collective" % (P, n, n, H, args.lanes),
+                   "descriptors": "sift", "k": 2, "distinct_pairs_per_rank": distinct},
+        "image_pairs_per_s": pairs_per_s,
+        "ransac": {"hyp_per_s": pairs_per_s * H, "hypotheses": H, "n_matches": int(res[0].n_good),
+                   "inliers": int(res[0].n_inliers)},
+        "pcie": {"h2d_bytes_per_pair": h2d, "h2d_GBps": pairs_per_s / world * h2d / 1e9,
+                 "note": "per-GPU host->device rate sustained by the pipeline; the inputs are 4.3 MB per pair"},
+        "parity": parity,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -46,9 +136,12 @@ def main():
     ap.add_argument("--hyps", type=int, default=10000)
     ap.add_argument("--kind", default="sift", choices=["sift", "surf", "orb"],
                     help="descriptor family: sift (u8-valued f32, BASELINE C3), surf (general f32), orb (256-bit, C4)")
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4"],
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5"],
                     help="BASELINE config: c3 (default, headline), c2 = 2k x 2k SIFT latency case, "
-                         "c4 = 32k x 32k ORB-256 + 100k hypotheses (per GPU: the multi-GPU run shards it)")
+                         "c4 = 32k x 32k ORB-256 + 100k hypotheses (per GPU: the multi-GPU run shards it), "
+                         "c5 = batch of 256 image pairs x 4k descriptors streamed end to end (pairs sharded over ranks)")
+    ap.add_argument("--pairs", type=int, default=256, help="c5: image pairs in the whole job")
+    ap.add_argument("--lanes", type=int, default=3, help="c5: streams (lanes) per GPU")
     ap.add_argument("--exercise-exchange", action="store_true",
                     help="debugging: run the N>1 code path (all-gather, concat, key all-reduce, model from key) "
                          "even with one rank")
@@ -84,6 +177,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
 
+    if args.workload == "c5":
+        return bench_c5(args, world, rank, local_rank, dev, multi, saved_stdout)
     if args.workload == "c2":
         args.nq = args.nt = 2048
     elif args.workload == "c4":

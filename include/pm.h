@@ -206,6 +206,41 @@ static inline uint64_t pm_ransac_key(uint32_t inliers, uint32_t hyp) {
 static inline uint32_t pm_ransac_key_hyp(uint64_t key)     { return 0xFFFFFFFFu - (uint32_t)key; }
 static inline uint32_t pm_ransac_key_inliers(uint64_t key) { return (uint32_t)(key >> 32); }
 
+/* ---- batch of independent image pairs (BASELINE config C5) ----------------------------------
+ * One pass of main.cpp:46 -> :49-69 (ratio form) -> :89-91 -> :95-98 per pair, streamed: the batch
+ * owns `n_lanes` contexts (stream + scratch + device buffers each); pair j runs on lane
+ * j % n_lanes, so H2D of the next pair, the kernels of this one and D2H of the previous one
+ * overlap.  Descriptors are f32 rows (L2 matcher, k = 2, `knn_flags` as pm_bf_knn_l2_f32);
+ * every pair uses the same ratio and RANSAC parameters.  Host pointers in the jobs should be
+ * page-locked (pm_host_register, or any hipHostMalloc'd / torch pinned buffer): pageable memory
+ * works but serialises the copies.  Blocking: returns when every result is in `results`
+ * (and, when non-NULL, `good`: n_jobs x max_n1 records, first n_good valid per pair; `masks`:
+ * n_jobs x max_n1 bytes, inlier flag per surviving match).  results[j].status is PM_OK,
+ * PM_E_TOO_FEW (fewer than 8 survivors) or PM_E_NO_MODEL. */
+typedef struct pm_pair_job {
+    const float* desc1;   /* n1 x dim, image-1 descriptors (query side of main.cpp:46) */
+    const float* desc2;   /* n2 x dim */
+    const float* kp1_xy;  /* n1 x 2 keypoint pixel coordinates */
+    const float* kp2_xy;  /* n2 x 2 */
+    int32_t n1, n2;
+} pm_pair_job;
+typedef struct pm_pair_result {
+    double   F[9];
+    uint64_t best_key;    /* pm_ransac_key of the winner, 0 if none */
+    int32_t  n_good;      /* survivors of the ratio test = correspondences given to RANSAC */
+    int32_t  n_inliers;
+    int32_t  status;
+    int32_t  reserved;
+} pm_pair_result;
+typedef struct pm_batch pm_batch;   /* opaque */
+int pm_batch_create(int device, int n_lanes, int max_n1, int max_n2, int dim, pm_batch** out);
+int pm_batch_destroy(pm_batch* b);
+int pm_batch_run(pm_batch* b, const pm_pair_job* jobs, int n_jobs, float ratio, int knn_flags,
+                 const pm_ransac_params* p, pm_pair_result* results, pm_match* good, uint8_t* masks);
+/* Page-lock / release a caller-owned host buffer (hipHostRegister) so the batch copies overlap. */
+int pm_host_register(void* ptr, size_t bytes);
+int pm_host_unregister(void* ptr);
+
 /* ---- residual report (main.cpp:103-123) -----------------------------------------------------
  * r[i] = [xa ya 1] * F * [xb yb 1]^T in fp64.  transposed != 0 reproduces the reference
  * literally ((xa,ya) = image-1 point, (xb,yb) = image-2 point: x1^T F x2, main.cpp:110-117);

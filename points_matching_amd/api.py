@@ -35,6 +35,7 @@ EXPORTS = [
     "pm_filter_ratio_gather_dev", "pm_concat_points_dev",
     "pm_ransac_fundamental", "pm_ransac_score_dev", "pm_ransac_score_devn", "pm_ransac_model_from_hyp",
     "pm_ransac_model_from_key_dev", "pm_ransac_run_dev",
+    "pm_batch_create", "pm_batch_destroy", "pm_batch_run", "pm_host_register", "pm_host_unregister",
     "pm_epipolar_residuals", "pm_f_scale_f33", "pm_epilines", "pm_epiline_endpoints",
 ]
 
@@ -323,3 +324,65 @@ class Context:
         prm = RansacParams(hyp_begin, hyp_end, seed, thresh_px, kind)
         _check(lib().pm_ransac_score_dev(self._h, C.c_void_p(dxy1_ptr), C.c_void_p(dxy2_ptr), n,
                                          C.byref(prm), C.c_void_p(dkey_ptr)))
+
+
+# ---- batch of image pairs (BASELINE config C5) ---------------------------------------------------
+
+class PairJob(C.Structure):
+    _fields_ = [("desc1", C.c_void_p), ("desc2", C.c_void_p), ("kp1_xy", C.c_void_p), ("kp2_xy", C.c_void_p),
+                ("n1", C.c_int32), ("n2", C.c_int32)]
+
+
+class PairResult(C.Structure):
+    _fields_ = [("F", C.c_double * 9), ("best_key", C.c_uint64), ("n_good", C.c_int32), ("n_inliers", C.c_int32),
+                ("status", C.c_int32), ("reserved", C.c_int32)]
+
+
+class PairBatch:
+    """pm_batch wrapper: `n_lanes` streams, each running whole pairs (H2D -> match -> ratio+gather ->
+    RANSAC-F -> D2H).  Jobs are (desc1_ptr, n1, desc2_ptr, n2, kp1_ptr, kp2_ptr) with HOST addresses
+    (ideally page-locked: torch pinned tensors, or host_register())."""
+
+    def __init__(self, device, n_lanes, max_n1, max_n2, dim):
+        self._h = C.c_void_p()
+        self.max_n1, self.dim = max_n1, dim
+        _check(lib().pm_batch_create(device, n_lanes, max_n1, max_n2, dim, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().pm_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def make_jobs(jobs):
+        arr = (PairJob * len(jobs))()
+        for a, (d1, n1, d2, n2, k1, k2) in zip(arr, jobs):
+            a.desc1, a.n1, a.desc2, a.n2, a.kp1_xy, a.kp2_xy = d1, n1, d2, n2, k1, k2
+        return arr
+
+    def run(self, jobs, ratio, iters, thresh_px, seed, knn_flags=0, kind=PM_ERR_SAMPSON, want_good=False,
+            want_masks=False):
+        """jobs: list of tuples or a prepared (PairJob * n) array.  Returns (results array, good, masks)."""
+        arr = jobs if isinstance(jobs, C.Array) else self.make_jobs(jobs)
+        n = len(arr)
+        res = (PairResult * n)()
+        good = np.zeros((n, self.max_n1), MATCH_DTYPE) if want_good else None
+        masks = np.zeros((n, self.max_n1), np.uint8) if want_masks else None
+        prm = RansacParams(0, iters, seed, thresh_px, kind)
+        _check(lib().pm_batch_run(self._h, arr, n, C.c_float(ratio), knn_flags, C.byref(prm), res,
+                                  _p(good) if want_good else None, _p(masks) if want_masks else None))
+        return res, good, masks
+
+
+def host_register(arr):
+    _check(lib().pm_host_register(C.c_void_p(arr.ctypes.data), arr.nbytes))
+
+
+def host_unregister(arr):
+    _check(lib().pm_host_unregister(C.c_void_p(arr.ctypes.data)))

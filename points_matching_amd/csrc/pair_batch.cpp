@@ -1,0 +1,192 @@
+// pair_batch.cpp — a batch of independent image pairs streamed end to end (BASELINE config C5:
+// 256 stereo pairs x 4k descriptors): per pair  H2D -> matcher -> ratio + gather -> RANSAC-F -> D2H,
+// i.e. one pass of main.cpp:46..98 per pair, with no host round trip inside a pair.
+//
+// A batch owns a few LANES.  A lane is one pm_ctx (its own HIP stream and scratch arena) plus the
+// lane's device buffers and a pinned result slot, so consecutive pairs run on different streams:
+// the copy engines move pair j+1 in and pair j-1 out while the kernels of pair j run, and the small
+// kernels of neighbouring pairs fill each other's tails.  The host thread only enqueues; it waits
+// for a lane when that lane's previous pair has to hand back its result slot.
+#include <new>
+
+#include "pm_common.hpp"
+
+namespace {
+
+struct DevResult {            // one D2H copy per pair
+    double F[9];
+    uint64_t key;
+    int32_t n_good;
+    int32_t n_inliers;
+};
+
+struct Lane {
+    pm_ctx* ctx = nullptr;
+    float *dq = nullptr, *dt = nullptr, *dkp1 = nullptr, *dkp2 = nullptr, *dxy1 = nullptr, *dxy2 = nullptr;
+    pm_match *dknn = nullptr, *dgood = nullptr;
+    uint8_t* dmask = nullptr;
+    DevResult* dres = nullptr;
+    // pinned
+    DevResult* hres = nullptr;
+    pm_match* hgood = nullptr;
+    uint8_t* hmask = nullptr;
+    hipEvent_t done = nullptr;
+    int pending = -1;          // job whose results sit in (or are on their way to) the pinned slot
+    int pending_n1 = 0;
+};
+
+}  // namespace
+
+struct pm_batch {
+    int device = 0, n_lanes = 0, max_n1 = 0, max_n2 = 0, dim = 0;
+    Lane* lanes = nullptr;
+};
+
+namespace {
+
+int lane_free(Lane& L)
+{
+    if (L.ctx) (void)hipStreamSynchronize(L.ctx->stream);
+    (void)hipFree(L.dq); (void)hipFree(L.dt); (void)hipFree(L.dkp1); (void)hipFree(L.dkp2);
+    (void)hipFree(L.dxy1); (void)hipFree(L.dxy2); (void)hipFree(L.dknn); (void)hipFree(L.dgood);
+    (void)hipFree(L.dmask); (void)hipFree(L.dres);
+    if (L.hres) (void)hipHostFree(L.hres);
+    if (L.hgood) (void)hipHostFree(L.hgood);
+    if (L.hmask) (void)hipHostFree(L.hmask);
+    if (L.done) (void)hipEventDestroy(L.done);
+    if (L.ctx) (void)pm_ctx_destroy(L.ctx);
+    L = Lane{};
+    return PM_OK;
+}
+
+int lane_init(Lane& L, int device, int max_n1, int max_n2, int dim)
+{
+    int rc = pm_ctx_create(device, &L.ctx);
+    if (rc != PM_OK) return rc;
+    const size_t n1 = static_cast<size_t>(max_n1), n2 = static_cast<size_t>(max_n2);
+    PM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&L.dq), sizeof(float) * n1 * dim));
+    PM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&L.dt), sizeof(float) * n2 * dim));
+    PM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&L.dkp1), sizeof(float) * 2 * n1));
+    PM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&L.dkp2), sizeof(float) * 2 * n2));
+    PM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&L.dxy1), sizeof(float) * 2 * n1));
+    PM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&L.dxy2), sizeof(float) * 2 * n1));
+    PM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&L.dknn), sizeof(pm_match) * 2 * n1));
+    PM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&L.dgood), sizeof(pm_match) * n1));
+    PM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&L.dmask), n1));
+    PM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&L.dres), sizeof(DevResult)));
+    PM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&L.hres), sizeof(DevResult), hipHostMallocDefault));
+    PM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&L.hgood), sizeof(pm_match) * n1, hipHostMallocDefault));
+    PM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&L.hmask), n1, hipHostMallocDefault));
+    PM_HIP_CHECK(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+    return PM_OK;
+}
+
+// hand the lane's finished pair back to the caller's arrays
+int lane_collect(pm_batch* b, Lane& L, pm_pair_result* results, pm_match* good, uint8_t* masks)
+{
+    if (L.pending < 0) return PM_OK;
+    PM_HIP_CHECK(hipEventSynchronize(L.done));
+    const int j = L.pending;
+    pm_pair_result& r = results[j];
+    memcpy(r.F, L.hres->F, sizeof(r.F));
+    r.best_key = L.hres->key;
+    r.n_good = L.hres->n_good;
+    r.n_inliers = L.hres->n_inliers;
+    r.status = r.n_good < 8 ? PM_E_TOO_FEW : (r.best_key == 0 ? PM_E_NO_MODEL : PM_OK);
+    if (good) memcpy(good + static_cast<size_t>(j) * b->max_n1, L.hgood, sizeof(pm_match) * static_cast<size_t>(r.n_good));
+    if (masks) memcpy(masks + static_cast<size_t>(j) * b->max_n1, L.hmask, static_cast<size_t>(L.pending_n1));
+    L.pending = -1;
+    return PM_OK;
+}
+
+}  // namespace
+
+extern "C" int pm_batch_create(int device, int n_lanes, int max_n1, int max_n2, int dim, pm_batch** out)
+{
+    PM_REQUIRE(out != nullptr, PM_E_INVALID, "out is null");
+    PM_REQUIRE(n_lanes >= 1 && n_lanes <= 16 && max_n1 >= 1 && max_n2 >= 1 && dim >= 1, PM_E_INVALID,
+               "need 1 <= n_lanes <= 16, max_n1, max_n2, dim >= 1");
+    PM_HIP_CHECK(hipSetDevice(device));
+    pm_batch* b = new (std::nothrow) pm_batch;
+    PM_REQUIRE(b != nullptr, PM_E_NOMEM, "out of host memory");
+    b->device = device; b->n_lanes = n_lanes; b->max_n1 = max_n1; b->max_n2 = max_n2; b->dim = dim;
+    b->lanes = new (std::nothrow) Lane[n_lanes];
+    if (!b->lanes) { delete b; pm::set_error("out of host memory"); return PM_E_NOMEM; }
+    for (int i = 0; i < n_lanes; ++i) {
+        const int rc = lane_init(b->lanes[i], device, max_n1, max_n2, dim);
+        if (rc != PM_OK) { (void)pm_batch_destroy(b); return rc; }
+    }
+    *out = b;
+    return PM_OK;
+}
+
+extern "C" int pm_batch_destroy(pm_batch* b)
+{
+    if (!b) return PM_OK;
+    (void)hipSetDevice(b->device);
+    for (int i = 0; i < b->n_lanes; ++i) lane_free(b->lanes[i]);
+    delete[] b->lanes;
+    delete b;
+    return PM_OK;
+}
+
+extern "C" int pm_batch_run(pm_batch* b, const pm_pair_job* jobs, int n_jobs, float ratio, int knn_flags,
+                            const pm_ransac_params* p, pm_pair_result* results, pm_match* good, uint8_t* masks)
+{
+    PM_REQUIRE(b != nullptr && p != nullptr, PM_E_INVALID, "null batch / params");
+    PM_REQUIRE(n_jobs >= 0 && (n_jobs == 0 || (jobs && results)), PM_E_INVALID, "null jobs / results");
+    for (int j = 0; j < n_jobs; ++j) {
+        const pm_pair_job& jb = jobs[j];
+        PM_REQUIRE(jb.n1 >= 1 && jb.n1 <= b->max_n1 && jb.n2 >= 1 && jb.n2 <= b->max_n2, PM_E_INVALID,
+                   "a pair exceeds the batch's max_n1 / max_n2 (or is empty)");
+        PM_REQUIRE(jb.desc1 && jb.desc2 && jb.kp1_xy && jb.kp2_xy, PM_E_INVALID, "null pointer in a pair job");
+    }
+    PM_HIP_CHECK(hipSetDevice(b->device));
+    int rc = PM_OK;
+    for (int j = 0; j < n_jobs && rc == PM_OK; ++j) {
+        Lane& L = b->lanes[j % b->n_lanes];
+        rc = lane_collect(b, L, results, good, masks);
+        if (rc != PM_OK) break;
+        const pm_pair_job& jb = jobs[j];
+        hipStream_t s = L.ctx->stream;
+        const size_t n1 = static_cast<size_t>(jb.n1), n2 = static_cast<size_t>(jb.n2);
+        PM_HIP_CHECK(hipMemcpyAsync(L.dq, jb.desc1, sizeof(float) * n1 * b->dim, hipMemcpyHostToDevice, s));
+        PM_HIP_CHECK(hipMemcpyAsync(L.dt, jb.desc2, sizeof(float) * n2 * b->dim, hipMemcpyHostToDevice, s));
+        PM_HIP_CHECK(hipMemcpyAsync(L.dkp1, jb.kp1_xy, sizeof(float) * 2 * n1, hipMemcpyHostToDevice, s));
+        PM_HIP_CHECK(hipMemcpyAsync(L.dkp2, jb.kp2_xy, sizeof(float) * 2 * n2, hipMemcpyHostToDevice, s));
+        rc = pm_bf_knn_l2_f32_dev(L.ctx, L.dq, jb.n1, L.dt, jb.n2, b->dim, 2, knn_flags, L.dknn);
+        if (rc == PM_OK)
+            rc = pm_filter_ratio_gather_dev(L.ctx, L.dknn, jb.n1, 2, ratio, L.dkp1, L.dkp2, L.dgood, L.dxy1, L.dxy2,
+                                            &L.dres->n_good);
+        if (rc == PM_OK)
+            rc = pm_ransac_run_dev(L.ctx, L.dxy1, L.dxy2, jb.n1, &L.dres->n_good, p, &L.dres->key, L.dres->F, L.dmask,
+                                   &L.dres->n_inliers);
+        if (rc != PM_OK) break;
+        PM_HIP_CHECK(hipMemcpyAsync(L.hres, L.dres, sizeof(DevResult), hipMemcpyDeviceToHost, s));
+        if (good) PM_HIP_CHECK(hipMemcpyAsync(L.hgood, L.dgood, sizeof(pm_match) * n1, hipMemcpyDeviceToHost, s));
+        if (masks) PM_HIP_CHECK(hipMemcpyAsync(L.hmask, L.dmask, n1, hipMemcpyDeviceToHost, s));
+        PM_HIP_CHECK(hipEventRecord(L.done, s));
+        L.pending = j;
+        L.pending_n1 = jb.n1;
+    }
+    // drain in job order (also after an error: nothing may stay in flight on the caller's buffers)
+    for (int i = 0; i < b->n_lanes; ++i) {
+        if (rc == PM_OK) rc = lane_collect(b, b->lanes[i], results, good, masks);
+        else { (void)hipStreamSynchronize(b->lanes[i].ctx->stream); b->lanes[i].pending = -1; }
+    }
+    return rc;
+}
+
+extern "C" int pm_host_register(void* ptr, size_t bytes)
+{
+    PM_REQUIRE(ptr != nullptr && bytes > 0, PM_E_INVALID, "null pointer / zero size");
+    PM_HIP_CHECK(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return PM_OK;
+}
+
+extern "C" int pm_host_unregister(void* ptr)
+{
+    PM_REQUIRE(ptr != nullptr, PM_E_INVALID, "null pointer");
+    PM_HIP_CHECK(hipHostUnregister(ptr));
+    return PM_OK;
+}

@@ -1,0 +1,77 @@
+"""GPU: pm_batch_run (BASELINE config C5: a batch of independent image pairs streamed over several
+lanes) against the CPU oracle run pair by pair: matches, F bits, inlier masks and keys identical,
+whatever the number of lanes."""
+import numpy as np
+import pytest
+
+import points_matching_amd as pm
+from points_matching_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(700, 640), (512, 900), (300, 300), (1024, 1024), (650, 40), (900, 777), (64, 2000)]
+H, TAU, SEED, RATIO = 600, 1.0, 0xC5, 0.8
+
+
+def _pairs():
+    out = []
+    for i, (n1, n2) in enumerate(SIZES):
+        w = synth.pair_workload(nq=n1, nt=n2, dim=128, seed=0xC5 + i, planted=0.5)
+        out.append(w)
+    return out
+
+
+def _oracle_pair(oracle, w):
+    knn = oracle.bf_knn_l2(w["q"], w["t"], 2)
+    good = oracle.filter_ratio(knn, RATIO)
+    xy1 = w["kp1"][good["queryIdx"]]
+    xy2 = w["kp2"][good["trainIdx"]]
+    rc, F, mask, ninl, key = oracle.ransac_fundamental(xy1, xy2, H, TAU, SEED)
+    return good, rc, F, mask, ninl, key
+
+
+@pytest.mark.parametrize("lanes", [1, 3])
+def test_batch_matches_oracle_pair_by_pair(oracle, lanes):
+    ws = _pairs()
+    max1 = max(s[0] for s in SIZES)
+    max2 = max(s[1] for s in SIZES)
+    b = pm.api.PairBatch(0, lanes, max1, max2, 128)
+    jobs = [(w["q"].ctypes.data, w["q"].shape[0], w["t"].ctypes.data, w["t"].shape[0],
+             w["kp1"].ctypes.data, w["kp2"].ctypes.data) for w in ws]
+    for rep in range(2):                       # the second run reuses every lane's buffers
+        res, good, masks = b.run(jobs, RATIO, H, TAU, SEED, want_good=True, want_masks=True)
+        for j, w in enumerate(ws):
+            g_o, rc_o, F_o, mask_o, ninl_o, key_o = _oracle_pair(oracle, w)
+            r = res[j]
+            assert r.n_good == g_o.size, (j, r.n_good, g_o.size)
+            got = good[j, :r.n_good]
+            assert (got["queryIdx"] == g_o["queryIdx"]).all() and (got["trainIdx"] == g_o["trainIdx"]).all()
+            assert (got["distance"].view(np.uint32) == g_o["distance"].view(np.uint32)).all()
+            if g_o.size < 8:
+                assert r.status == pm.api.PM_E_TOO_FEW and r.best_key == 0
+                continue
+            assert r.status == rc_o == pm.api.PM_OK
+            assert r.best_key == key_o and r.n_inliers == ninl_o, (j, r.best_key, key_o)
+            assert (np.array(r.F[:]).view(np.uint64) == F_o.reshape(9).view(np.uint64)).all()
+            assert (masks[j, :r.n_good] == mask_o).all() and not masks[j, r.n_good:w["q"].shape[0]].any()
+    b.close()
+
+
+def test_batch_pinned_inputs_and_argument_checks():
+    w = synth.pair_workload(nq=256, nt=256, dim=128, seed=3, planted=0.5)
+    bufs = [w["q"], w["t"], w["kp1"], w["kp2"]]
+    for a in bufs:
+        pm.api.host_register(a)
+    b = pm.api.PairBatch(0, 2, 256, 256, 128)
+    job = (w["q"].ctypes.data, 256, w["t"].ctypes.data, 256, w["kp1"].ctypes.data, w["kp2"].ctypes.data)
+    res, _, _ = b.run([job] * 5, RATIO, 200, TAU, 1)
+    assert len({(r.best_key, r.n_good, r.n_inliers, bytes(r.F)) for r in res}) == 1      # same pair, same answer
+    with pytest.raises(pm.PmError):
+        b.run([(job[0], 257, job[2], 256, job[4], job[5])], RATIO, 200, TAU, 1)           # exceeds max_n1
+    with pytest.raises(pm.PmError):
+        b.run([(0, 256, job[2], 256, job[4], job[5])], RATIO, 200, TAU, 1)                # null descriptors
+    res, _, _ = b.run([], RATIO, 200, TAU, 1)
+    assert len(res) == 0
+    b.close()
+    for a in bufs:
+        pm.api.host_unregister(a)

@@ -21,5 +21,6 @@ ctx.timing_enable(True); ctx.timing_reset()
 for _ in range(reps):
     ctx.bf_knn_hamming_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, 32, 2, d_out.data_ptr())
 torch.cuda.synchronize()
-ms = ctx.timing_get("knn_hamming")[0]; mm = ctx.timing_get("knn_hamming_merge")[0]
-print("hamming", nq, nt, "scan_us", round(ms*1e3,1), "merge_us", round(mm*1e3,1), "pairs/s %.3e" % (nq*nt/((ms+mm)*1e-3)))
+t = {k: ctx.timing_get(k)[0] for k in ("knn_hamming_expand", "knn_hamming_mfma_i8", "knn_hamming_refine", "knn_hamming",
+                                       "knn_hamming_merge")}
+print("hamming", nq, nt, {k: round(v * 1e3, 1) for k, v in t.items()}, "pairs/s %.3e" % (nq * nt / (sum(t.values()) * 1e-3)))
