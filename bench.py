@@ -43,10 +43,10 @@ def bench_c5(args, world, rank, local_rank, dev, multi, saved_stdout):
     import torch
     import torch.distributed as dist
     import points_matching_amd as pm
-    from points_matching_amd import synth
+    from points_matching_amd import shard, synth
 
     n, dim, H, ratio, thresh, seed = 4096, 128, 2048, 0.8, 1.0, 0x5EED
-    my_pairs = [p for p in range(args.pairs) if p % world == rank]
+    my_pairs = shard.pair_shard(args.pairs, rank, world)
     distinct = min(len(my_pairs), 16)          # distinct synthetic pairs held in pinned memory, cycled
     hold = []
     for i in range(distinct):

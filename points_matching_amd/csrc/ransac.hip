@@ -20,6 +20,8 @@
 // Every operation below is written in the order docs/SPEC.md fixes (explicit fma, unfused
 // elsewhere; the TU is built with -ffp-contract=off) so that the CPU restatement reproduces the
 // same bits.
+#include <cstdlib>
+
 #include "pm_common.hpp"
 
 namespace {
@@ -348,7 +350,9 @@ __device__ __forceinline__ void publish_model(FinalOut* __restrict__ fo, double*
     if (n_out) *n_out = 0;
 }
 
-constexpr int SCORE_CHUNK = 256;      // correspondences staged per workgroup (4 KB of LDS)
+constexpr int SCORE_CHUNK = 256;      // correspondences staged per pass (4 KB of LDS)
+constexpr int SCORE_MIN_CHUNK = 128;  // smaller chunks = more counter atomics and tickets: slower even though the chip is
+                                      // underfilled (C3: 96 -> 29.8 us, 128 -> 24.6, 160 -> 24.3, 256 -> 25.9)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -400,7 +404,7 @@ struct FusedTail {
 // workgroups read counters/keys with agent-scope loads (CDNA guide, Guideline 16).
 template <int KIND, bool FUSED>
 __global__ __launch_bounds__(256) void ransac_score(const float* __restrict__ xy1, const float* __restrict__ xy2,
-                                                    int n_max, const int* __restrict__ d_n, int chunk_len,
+                                                    int n_max, const int* __restrict__ d_n, int min_chunk,
                                                     const float* __restrict__ models, int nh, float thr2,
                                                     int* __restrict__ counts, FusedTail ft)
 {
@@ -409,45 +413,69 @@ __global__ __launch_bounds__(256) void ransac_score(const float* __restrict__ xy
     const int n = resolve_n(n_max, d_n);
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int tl = t < nh ? t : nh - 1;
+    const int tt = threadIdx.x;
+    // The correspondences are cut into chunks of chunk_len (<= SCORE_CHUNK, even, chosen here from the
+    // DEVICE-side count so that the gridDim.y workgroup columns all have work), column y taking chunks
+    // y, y + gridDim.y, ...: few big chunks when there are many hypothesis blocks (prologue, counter
+    // update and ticket amortised), more, smaller ones when there are few.
+    const int ycols = static_cast<int>(gridDim.y);
+    int chunk_len = ((n + ycols - 1) / ycols + 1) & ~1;
+    chunk_len = chunk_len < min_chunk ? min_chunk : (chunk_len > SCORE_CHUNK ? SCORE_CHUNK : chunk_len);
+    // columns past the last chunk have nothing to add: they leave at once and are not counted by the
+    // tickets (column 0 always stays, so that the tail runs even for an empty input)
+    int active = (n + chunk_len - 1) / chunk_len;
+    active = active < 1 ? 1 : (active > ycols ? ycols : active);
+    if (static_cast<int>(blockIdx.y) >= active) return;
+    const int stride = active * chunk_len;
+    int i0 = blockIdx.y * chunk_len;
+    // this thread's point of the first chunk is requested BEFORE the model, and the next chunk's
+    // point while the current chunk is scored: neither load sits behind the other's wait
+    float2 sp = {0.f, 0.f}, spp = sp;
+    if (i0 < n) {
+        const int idx = i0 + tt < n ? i0 + tt : n - 1;           // clamped: the load stays unconditional
+        sp = *reinterpret_cast<const float2*>(xy1 + 2 * static_cast<size_t>(idx));
+        spp = *reinterpret_cast<const float2*>(xy2 + 2 * static_cast<size_t>(idx));
+    }
     float f[9];
     const float* m = models + static_cast<size_t>(tl) * MODEL_STRIDE;
 #pragma unroll
     for (int i = 0; i < 9; ++i) f[i] = m[i];
-    const int i0 = blockIdx.y * chunk_len;
-    int i1 = i0 + chunk_len;
-    if (i1 > n) i1 = n;
-    const int len = i1 - i0;                    // <= SCORE_CHUNK, may be <= 0 past the device count
-    const int len2 = (len + 1) & ~1;
-    // one coalesced pass into LDS; every lane then reads the same address (broadcast), so a pair of
-    // points costs two ds_read_b128 per wave.  An odd tail is padded with NaN (never an inlier).
-    {
-        const int tt = threadIdx.x;
-        if (tt < len2) {
-            float2 p = {__builtin_nanf(""), __builtin_nanf("")}, pp = p;
-            if (tt < len) {
-                p = *reinterpret_cast<const float2*>(xy1 + 2 * static_cast<size_t>(i0 + tt));
-                pp = *reinterpret_cast<const float2*>(xy2 + 2 * static_cast<size_t>(i0 + tt));
-            }
-            float* d = pts + (tt >> 1) * 8 + (tt & 1);
-            d[0] = p.x; d[2] = p.y; d[4] = pp.x; d[6] = pp.y;
-        }
-    }
-    __syncthreads();
     int cnt = 0;
-    const int npair = len2 >> 1;
-    int p = 0;
-    for (; p + 2 <= npair; p += 2) {
-        const f32x4v u0 = *reinterpret_cast<const f32x4v*>(pts + p * 8);
-        const f32x4v v0 = *reinterpret_cast<const f32x4v*>(pts + p * 8 + 4);
-        const f32x4v u1 = *reinterpret_cast<const f32x4v*>(pts + p * 8 + 8);
-        const f32x4v v1 = *reinterpret_cast<const f32x4v*>(pts + p * 8 + 12);
-        cnt += inlier32_x2<KIND>(f, f32x2{u0[0], u0[1]}, f32x2{u0[2], u0[3]}, f32x2{v0[0], v0[1]}, f32x2{v0[2], v0[3]}, thr2);
-        cnt += inlier32_x2<KIND>(f, f32x2{u1[0], u1[1]}, f32x2{u1[2], u1[3]}, f32x2{v1[0], v1[1]}, f32x2{v1[2], v1[3]}, thr2);
-    }
-    for (; p < npair; ++p) {
-        const f32x4v u0 = *reinterpret_cast<const f32x4v*>(pts + p * 8);
-        const f32x4v v0 = *reinterpret_cast<const f32x4v*>(pts + p * 8 + 4);
-        cnt += inlier32_x2<KIND>(f, f32x2{u0[0], u0[1]}, f32x2{u0[2], u0[3]}, f32x2{v0[0], v0[1]}, f32x2{v0[2], v0[3]}, thr2);
+    for (; i0 < n; i0 += stride) {
+        int i1 = i0 + chunk_len;
+        if (i1 > n) i1 = n;
+        const int len = i1 - i0;
+        const int len2 = (len + 1) & ~1;
+        // one coalesced pass into LDS; every lane then reads the same address (broadcast), so a pair of
+        // points costs two ds_read_b128 per wave.  An odd tail is padded with NaN (never an inlier).
+        if (tt < len2) {
+            const float nanv = __builtin_nanf("");
+            const bool real = tt < len;
+            float* d = pts + (tt >> 1) * 8 + (tt & 1);
+            d[0] = real ? sp.x : nanv; d[2] = real ? sp.y : nanv; d[4] = real ? spp.x : nanv; d[6] = real ? spp.y : nanv;
+        }
+        if (i0 + stride < n) {
+            const int idx = i0 + stride + tt < n ? i0 + stride + tt : n - 1;
+            sp = *reinterpret_cast<const float2*>(xy1 + 2 * static_cast<size_t>(idx));
+            spp = *reinterpret_cast<const float2*>(xy2 + 2 * static_cast<size_t>(idx));
+        }
+        __syncthreads();
+        const int npair = len2 >> 1;
+        int p = 0;
+        for (; p + 2 <= npair; p += 2) {
+            const f32x4v u0 = *reinterpret_cast<const f32x4v*>(pts + p * 8);
+            const f32x4v v0 = *reinterpret_cast<const f32x4v*>(pts + p * 8 + 4);
+            const f32x4v u1 = *reinterpret_cast<const f32x4v*>(pts + p * 8 + 8);
+            const f32x4v v1 = *reinterpret_cast<const f32x4v*>(pts + p * 8 + 12);
+            cnt += inlier32_x2<KIND>(f, f32x2{u0[0], u0[1]}, f32x2{u0[2], u0[3]}, f32x2{v0[0], v0[1]}, f32x2{v0[2], v0[3]}, thr2);
+            cnt += inlier32_x2<KIND>(f, f32x2{u1[0], u1[1]}, f32x2{u1[2], u1[3]}, f32x2{v1[0], v1[1]}, f32x2{v1[2], v1[3]}, thr2);
+        }
+        for (; p < npair; ++p) {
+            const f32x4v u0 = *reinterpret_cast<const f32x4v*>(pts + p * 8);
+            const f32x4v v0 = *reinterpret_cast<const f32x4v*>(pts + p * 8 + 4);
+            cnt += inlier32_x2<KIND>(f, f32x2{u0[0], u0[1]}, f32x2{u0[2], u0[3]}, f32x2{v0[0], v0[1]}, f32x2{v0[2], v0[3]}, thr2);
+        }
+        __syncthreads();                        // the stage is rewritten by the next chunk
     }
     if (t < nh && cnt) atomicAdd(&counts[t], cnt);
     if (!FUSED) return;
@@ -461,7 +489,7 @@ __global__ __launch_bounds__(256) void ransac_score(const float* __restrict__ xy
     __syncthreads();
     if (threadIdx.x == 0) {
         const int tk = __hip_atomic_fetch_add(&ft.tickets[1 + blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        role = tk == static_cast<int>(gridDim.y) - 1 ? 1 : 0;
+        role = tk == active - 1 ? 1 : 0;
     }
     __syncthreads();
     if (role == 0) return;
@@ -639,16 +667,16 @@ int score_shard(pm_ctx* ctx, const float* dxy1, const float* dxy2, int n, const 
                            p->hyp_begin, nh, sc.models, sc.models64, sc.counts, d_key, sc.tickets, sc.n_tickets);
         PM_HIP_CHECK(hipGetLastError());
     }
+    // workgroup columns over the correspondences: about 10 workgroups per CU in total, never more
+    // columns than minimum-size chunks of the largest possible count
     const int hb = (nh + 255) / 256;
-    int chunks = (8 * ctx->n_cu + hb - 1) / hb;
-    const int max_chunks = (n + 15) / 16;
-    const int min_chunks = (n + SCORE_CHUNK - 1) / SCORE_CHUNK;          // a chunk must fit the LDS stage
+    static const int wgs_per_cu = [] { const char* e = getenv("PM_SCORE_WGS_PER_CU"); return e ? atoi(e) : 16; }();
+    int chunks = (wgs_per_cu * ctx->n_cu + hb - 1) / hb;
+    static const int min_chunk = [] { const char* e = getenv("PM_SCORE_MIN_CHUNK"); return e ? atoi(e) : SCORE_MIN_CHUNK; }();
+    const int max_chunks = (n + min_chunk - 1) / min_chunk;
     if (chunks > max_chunks) chunks = max_chunks;
-    if (chunks < min_chunks) chunks = min_chunks;
     if (chunks < 1) chunks = 1;
-    const int chunk_len = (n + chunks - 1) / chunks;
-    chunks = (n + chunk_len - 1) / chunk_len;
-    PM_REQUIRE(chunks <= 65535, PM_E_UNSUPPORTED, "more than 16.7M correspondences per RANSAC call");
+    if (chunks > 65535) chunks = 65535;
     const float thr2 = p->thresh_px * p->thresh_px;
     {
         pm::ScopedKernelTime t(ctx, "ransac_score");
@@ -656,7 +684,7 @@ int score_shard(pm_ctx* ctx, const float* dxy1, const float* dxy2, int n, const 
         const FusedTail& ft = fused ? *fused : none;
 #define PM_SCORE(KIND_, FUSED_)                                                                                    \
     hipLaunchKernelGGL((ransac_score<KIND_, FUSED_>), dim3(hb, chunks), dim3(256), 0, ctx->stream, dxy1, dxy2, n, d_n, \
-                       chunk_len, sc.models, nh, thr2, sc.counts, ft)
+                       min_chunk, sc.models, nh, thr2, sc.counts, ft)
         if (p->error_kind == PM_ERR_SAMPSON) { if (fused) PM_SCORE(PM_ERR_SAMPSON, true); else PM_SCORE(PM_ERR_SAMPSON, false); }
         else { if (fused) PM_SCORE(PM_ERR_SYM_EPIPOLAR, true); else PM_SCORE(PM_ERR_SYM_EPIPOLAR, false); }
 #undef PM_SCORE

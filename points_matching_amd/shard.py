@@ -20,6 +20,12 @@ def hyp_shard(n_hyp, rank, world):
     return rank * n_hyp // world, (rank + 1) * n_hyp // world
 
 
+def pair_shard(n_pairs, rank, world):
+    """Image pairs of a batch owned by `rank` (config C5): pair p -> rank p mod world.  Independent
+    units: no collective on the data path."""
+    return list(range(rank, n_pairs, world))
+
+
 def reduce_key(key):
     """key: int64 tensor of one element (this rank's best key).  In-place global max."""
     if dist.is_initialized() and dist.get_world_size() > 1:

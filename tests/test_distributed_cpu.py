@@ -72,3 +72,12 @@ def test_hyp_shard_partitions():
             r = [shard.hyp_shard(H, g, world) for g in range(world)]
             assert r[0][0] == 0 and r[-1][1] == H
             assert all(r[i][1] == r[i + 1][0] for i in range(world - 1))
+
+
+def test_pair_shard_partitions():
+    from points_matching_amd import shard
+    for P in (1, 5, 256):
+        for world in (1, 2, 3, 8):
+            parts = [shard.pair_shard(P, g, world) for g in range(world)]
+            assert sorted(p for part in parts for p in part) == list(range(P))
+            assert max(len(x) for x in parts) - min(len(x) for x in parts) <= 1
