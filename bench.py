@@ -35,6 +35,20 @@ PEAK_F32_VALU_TFLOPS = 157.3
 PEAK_F16_MFMA_TFLOPS = 2500.0    # dense f16/bf16 MFMA (spec; the 5 PF headline includes 2:1 sparsity)
 
 
+def pmc_traffic(key, nq, nt):
+    """HBM bytes per launch of the dominant kernel, from the committed PMC passes (profiles/r01_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction applied).  PMC counters cannot be
+    read from inside this process, so the figure is the profiled one for exactly this workload, else null."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    want = {"c3:knn_l2_mfma_f16": (8192, 8192), "c3_f32:knn_l2_mfma": (8192, 8192), "c4:knn_hamming_mfma_i8": (32768, 32768)}
+    if key in t and want.get(key) == (nq, nt):
+        return t[key]["traffic_bytes"]
+    return None
+
+
 def bench_c5(args, world, rank, local_rank, dev, multi, saved_stdout):
     """BASELINE configs[4]: a batch of 256 independent image pairs x 4096 SIFT-128 descriptors, H = 2048
     hypotheses per pair, streamed end to end INCLUDING H2D of the descriptors/keypoints and D2H of the
@@ -367,7 +381,8 @@ def main():
         ach = ops / (kern["knn_hamming_mfma_i8"] * 1e-6) / 1e12
         out["roofline"] = {"kernel": "knn_hamming_mfma_i8 (knn_mfma_rows288<RouteI8>)", "bound": "mfma", "achieved": ach,
                            "peak": 2 * PEAK_F16_MFMA_TFLOPS, "unit": "TOP/s", "frac": ach / (2 * PEAK_F16_MFMA_TFLOPS),
-                           "traffic": None,
+                           "traffic": pmc_traffic("c4:knn_hamming_mfma_i8", nq, nt),
+                           "algorithmic_bytes": (nq + nt) * dim + nq * K * 16,
                            "dtype": "i8 (+-1 expanded bits) x i8 -> i32 MFMA; exact",
                            "note": "the kernel issues 9 k-chunks per 8 data chunks (pad-row seed): 12.5% of the "
                                    "issued MFMAs are not algorithmic work"}
@@ -381,21 +396,30 @@ def main():
                            "dtype": "u32 xor + popcount on the VALU (v_xor_b32, v_bcnt_u32_b32)"}
     elif kern.get("knn_l2_mfma_f16", 0) > kern.get("knn_l2_mfma", 0):
         ach = flops / (kern["knn_l2_mfma_f16"] * 1e-6) / 1e12
-        out["roofline"] = {"kernel": "knn_l2_mfma_f16", "bound": "mfma", "achieved": ach, "peak": PEAK_F16_MFMA_TFLOPS,
-                           "unit": "TFLOP/s", "frac": ach / PEAK_F16_MFMA_TFLOPS, "traffic": None,
+        out["roofline"] = {"kernel": "knn_l2_mfma_f16 (knn_mfma_rows288<RouteF16>)", "bound": "mfma", "achieved": ach,
+                           "peak": PEAK_F16_MFMA_TFLOPS,
+                           "unit": "TFLOP/s", "frac": ach / PEAK_F16_MFMA_TFLOPS,
+                           "traffic": pmc_traffic("c3:knn_l2_mfma_f16", nq, nt),
+                           "algorithmic_bytes": (nq + nt) * dim * 4 + nq * K * 16,
                            "dtype": "f16-input MFMA, f32 accumulate (v_mfma_f32_32x32x16_f16), exact for u8-valued data",
                            "note": "VALU-issue bound: the grouped top-4 selection costs 1.75 VALU ops per pair next to "
                                    "9 MFMAs per 1024 pairs; see DESIGN.md"}
     elif "knn_l2_mfma" in kern:
         ach = flops / (kern["knn_l2_mfma"] * 1e-6) / 1e12
         out["roofline"] = {"kernel": "knn_l2_mfma", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                           "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                           "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                           "traffic": pmc_traffic("c3_f32:knn_l2_mfma", nq, nt),
+                           "algorithmic_bytes": (nq + nt) * dim * 4 + nq * K * 16,
                            "dtype": "f32-input MFMA (v_mfma_f32_32x32x2_f32)"}
+    if out.get("roofline", {}).get("traffic") is not None:
+        out["roofline"]["traffic_source"] = "profiles/r01_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this " \
+                                            "kernel on this workload (separate passes, gfx950 correction); not re-measured live"
     if f32_route_us > 0:
         ach = flops / (f32_route_us * 1e-6) / 1e12
         out["roofline_f32_route"] = {"kernel": "knn_l2_mfma", "bound": "mfma", "achieved": ach,
                                      "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
                                      "kernel_us": round(f32_route_us, 2),
+                                     "traffic": pmc_traffic("c3_f32:knn_l2_mfma", nq, nt),
                                      "dtype": "f32-input MFMA (v_mfma_f32_32x32x2_f32): coarse route for general floats"}
     if "ransac_score" in kern and n_m:
         flops = 34.0 * n_m * (he - hb)
