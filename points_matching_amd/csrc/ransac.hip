@@ -277,6 +277,11 @@ __device__ __forceinline__ int resolve_n(int n_max, const int* __restrict__ d_n)
     return v < n_max ? (v < 0 ? 0 : v) : n_max;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x8v __attribute__((ext_vector_type(8)));
+constexpr int PAIR_PAD = 8;          // NaN records behind the last pair: the scalar-operand scorer prefetches past its range
+
 // Scratch of one shard: fp32 models for the scorer, fp64 models for a local finalisation,
 // inlier counters.  The solve kernel also clears the counters and the shard key, so the run
 // needs no memset nodes.
@@ -285,14 +290,36 @@ __global__ __launch_bounds__(64) void ransac_solve(const float* __restrict__ xy1
                                                    int64_t hyp_begin, int nh, float* __restrict__ models,
                                                    double* __restrict__ models64, int* __restrict__ counts,
                                                    unsigned long long* __restrict__ key, int* __restrict__ tickets,
-                                                   int n_tickets)
+                                                   int n_tickets, float* __restrict__ pairs)
 {
     const int t = blockIdx.x * 64 + threadIdx.x;
     if (t == 0) *key = 0ull;
     if (t < n_tickets) tickets[t] = 0;          // arrival counters of the fused scorer (grid >= n_tickets threads)
+    const int n = resolve_n(n_max, d_n);
+    // pair records for the scorer: record r = (x_a, x_b, y_a, y_b, x'_a, x'_b, y'_a, y'_b) of points
+    // a = 2r, b = 2r+1; an odd tail and PAIR_PAD records behind the end are NaN (never inliers)
+    if (pairs) {
+        const int nrec = (n + 1) / 2 + PAIR_PAD;
+        for (int r = t; r < nrec; r += static_cast<int>(gridDim.x) * 64) {
+            const float nanv = __builtin_nanf("");
+            const int a = 2 * r, b = 2 * r + 1;
+            const int ac = a < n ? a : 0, bc = b < n ? b : 0;                 // clamped: unconditional loads (n >= 1 below)
+            float2 pa = {nanv, nanv}, qa = pa, pb = pa, qb = pa;
+            if (n > 0) {
+                pa = *reinterpret_cast<const float2*>(xy1 + 2 * static_cast<size_t>(ac));
+                qa = *reinterpret_cast<const float2*>(xy2 + 2 * static_cast<size_t>(ac));
+                pb = *reinterpret_cast<const float2*>(xy1 + 2 * static_cast<size_t>(bc));
+                qb = *reinterpret_cast<const float2*>(xy2 + 2 * static_cast<size_t>(bc));
+            }
+            const bool va = a < n, vb = b < n;
+            f32x4v lo = {va ? pa.x : nanv, vb ? pb.x : nanv, va ? pa.y : nanv, vb ? pb.y : nanv};
+            f32x4v hi = {va ? qa.x : nanv, vb ? qb.x : nanv, va ? qa.y : nanv, vb ? qb.y : nanv};
+            *reinterpret_cast<f32x4v*>(pairs + 8 * static_cast<size_t>(r)) = lo;
+            *reinterpret_cast<f32x4v*>(pairs + 8 * static_cast<size_t>(r) + 4) = hi;
+        }
+    }
     if (t >= nh) return;
     counts[t] = 0;
-    const int n = resolve_n(n_max, d_n);
     float* m = models + static_cast<size_t>(t) * MODEL_STRIDE;
     if (n < 8) { m[9] = 0.f; return; }
     double F[9];
@@ -354,8 +381,6 @@ constexpr int SCORE_CHUNK = 256;      // correspondences staged per pass (4 KB o
 constexpr int SCORE_MIN_CHUNK = 128;  // smaller chunks = more counter atomics and tickets: slower even though the chip is
                                       // underfilled (C3: 96 -> 29.8 us, 128 -> 24.6, 160 -> 24.3, 256 -> 25.9)
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 // SPEC S8 on TWO correspondences at once: every operation is the packed-f32 form of the scalar
 // one (v_pk_fma_f32 / v_pk_mul_f32 are IEEE per component, so the bits equal inlier32), which
@@ -402,9 +427,9 @@ struct FusedTail {
 // order is whatever it is: every counter is an agent-scope atomic, each wave drains its own
 // atomics (s_waitcnt vmcnt(0)) before the workgroup's ticket is drawn, and the finishing
 // workgroups read counters/keys with agent-scope loads (CDNA guide, Guideline 16).
-template <int KIND, bool FUSED>
+template <int KIND, bool FUSED, bool SMEM>
 __global__ __launch_bounds__(256) void ransac_score(const float* __restrict__ xy1, const float* __restrict__ xy2,
-                                                    int n_max, const int* __restrict__ d_n, int min_chunk,
+                                                    const float* __restrict__ pairs, int n_max, const int* __restrict__ d_n, int min_chunk,
                                                     const float* __restrict__ models, int nh, float thr2,
                                                     int* __restrict__ counts, FusedTail ft)
 {
@@ -420,7 +445,8 @@ __global__ __launch_bounds__(256) void ransac_score(const float* __restrict__ xy
     // update and ticket amortised), more, smaller ones when there are few.
     const int ycols = static_cast<int>(gridDim.y);
     int chunk_len = ((n + ycols - 1) / ycols + 1) & ~1;
-    chunk_len = chunk_len < min_chunk ? min_chunk : (chunk_len > SCORE_CHUNK ? SCORE_CHUNK : chunk_len);
+    if (SMEM) chunk_len = chunk_len < 64 ? 64 : chunk_len;      // no LDS stage: one contiguous range per column
+    else chunk_len = chunk_len < min_chunk ? min_chunk : (chunk_len > SCORE_CHUNK ? SCORE_CHUNK : chunk_len);
     // columns past the last chunk have nothing to add: they leave at once and are not counted by the
     // tickets (column 0 always stays, so that the tail runs even for an empty input)
     int active = (n + chunk_len - 1) / chunk_len;
@@ -428,54 +454,96 @@ __global__ __launch_bounds__(256) void ransac_score(const float* __restrict__ xy
     if (static_cast<int>(blockIdx.y) >= active) return;
     const int stride = active * chunk_len;
     int i0 = blockIdx.y * chunk_len;
-    // this thread's point of the first chunk is requested BEFORE the model, and the next chunk's
-    // point while the current chunk is scored: neither load sits behind the other's wait
     float2 sp = {0.f, 0.f}, spp = sp;
-    if (i0 < n) {
-        const int idx = i0 + tt < n ? i0 + tt : n - 1;           // clamped: the load stays unconditional
-        sp = *reinterpret_cast<const float2*>(xy1 + 2 * static_cast<size_t>(idx));
-        spp = *reinterpret_cast<const float2*>(xy2 + 2 * static_cast<size_t>(idx));
+    if (!SMEM) {
+        // this thread's point of the first chunk is requested BEFORE the model, and the next chunk's
+        // point while the current chunk is scored: neither load sits behind the other's wait
+        if (i0 < n) {
+            const int idx = i0 + tt < n ? i0 + tt : n - 1;           // clamped: the load stays unconditional
+            sp = *reinterpret_cast<const float2*>(xy1 + 2 * static_cast<size_t>(idx));
+            spp = *reinterpret_cast<const float2*>(xy2 + 2 * static_cast<size_t>(idx));
+        }
     }
     float f[9];
     const float* m = models + static_cast<size_t>(tl) * MODEL_STRIDE;
 #pragma unroll
     for (int i = 0; i < 9; ++i) f[i] = m[i];
     int cnt = 0;
-    for (; i0 < n; i0 += stride) {
-        int i1 = i0 + chunk_len;
-        if (i1 > n) i1 = n;
-        const int len = i1 - i0;
-        const int len2 = (len + 1) & ~1;
-        // one coalesced pass into LDS; every lane then reads the same address (broadcast), so a pair of
-        // points costs two ds_read_b128 per wave.  An odd tail is padded with NaN (never an inlier).
-        if (tt < len2) {
-            const float nanv = __builtin_nanf("");
-            const bool real = tt < len;
-            float* d = pts + (tt >> 1) * 8 + (tt & 1);
-            d[0] = real ? sp.x : nanv; d[2] = real ? sp.y : nanv; d[4] = real ? spp.x : nanv; d[6] = real ? spp.y : nanv;
+    if (SMEM) {
+        // Correspondences as SCALAR operands: the pair records written by ransac_solve are wave-uniform,
+        // so they arrive through the scalar cache (s_load_dwordx8) and feed v_pk_fma_f32 as SGPR pairs —
+        // no LDS staging, no broadcast ds_reads, no barriers.  Four records are in flight while four
+        // are scored (SMEM returns out of order: a wait covers everything outstanding).
+        const f32x8v* __restrict__ P = reinterpret_cast<const f32x8v*>(pairs);
+#define PM_X2(c) inlier32_x2<KIND>(f, f32x2{c[0], c[1]}, f32x2{c[2], c[3]}, f32x2{c[4], c[5]}, f32x2{c[6], c[7]}, thr2)
+        // PM_AFTER(idx, r0, r1): the loads at record idx are requested only after the set (r0, r1) has
+        // ARRIVED and the previous set is fully scored (the empty asm consumes the count, passes the set
+        // through and produces idx), so the wait for the set in use never covers the set in flight and
+        // the scheduler cannot pull the next set's arithmetic in front of that wait
+#define PM_AFTER(idx, r0, r1) asm volatile("" : "+s"(idx), "+s"(r0), "+s"(r1) : "v"(cnt))
+        for (; i0 < n; i0 += stride) {
+            int i1 = i0 + chunk_len;
+            if (i1 > n) i1 = n;
+            int p = i0 >> 1;
+            const int p1 = (i1 + 1) >> 1;
+            f32x8v a0 = P[p], a1 = P[p + 1], b0, b1;
+            for (; p + 4 <= p1; p += 4) {
+                int ob = p + 2;
+                PM_AFTER(ob, a0, a1);
+                b0 = P[ob]; b1 = P[ob + 1];
+                __builtin_amdgcn_sched_barrier(0);          // the request stays HERE, ahead of the scoring of a
+                cnt += PM_X2(a0);
+                cnt += PM_X2(a1);
+                int oa = p + 4;
+                PM_AFTER(oa, b0, b1);
+                a0 = P[oa]; a1 = P[oa + 1];
+                __builtin_amdgcn_sched_barrier(0);
+                cnt += PM_X2(b0);
+                cnt += PM_X2(b1);
+            }
+            if (p < p1) cnt += PM_X2(a0);
+            if (p + 1 < p1) cnt += PM_X2(a1);
+            if (p + 2 < p1) { b0 = P[p + 2]; cnt += PM_X2(b0); }
         }
-        if (i0 + stride < n) {
-            const int idx = i0 + stride + tt < n ? i0 + stride + tt : n - 1;
-            sp = *reinterpret_cast<const float2*>(xy1 + 2 * static_cast<size_t>(idx));
-            spp = *reinterpret_cast<const float2*>(xy2 + 2 * static_cast<size_t>(idx));
+#undef PM_AFTER
+#undef PM_X2
+    } else {
+        for (; i0 < n; i0 += stride) {
+            int i1 = i0 + chunk_len;
+            if (i1 > n) i1 = n;
+            const int len = i1 - i0;
+            const int len2 = (len + 1) & ~1;
+            // one coalesced pass into LDS; every lane then reads the same address (broadcast), so a pair of
+            // points costs two ds_read_b128 per wave.  An odd tail is padded with NaN (never an inlier).
+            if (tt < len2) {
+                const float nanv = __builtin_nanf("");
+                const bool real = tt < len;
+                float* d = pts + (tt >> 1) * 8 + (tt & 1);
+                d[0] = real ? sp.x : nanv; d[2] = real ? sp.y : nanv; d[4] = real ? spp.x : nanv; d[6] = real ? spp.y : nanv;
+            }
+            if (i0 + stride < n) {
+                const int idx = i0 + stride + tt < n ? i0 + stride + tt : n - 1;
+                sp = *reinterpret_cast<const float2*>(xy1 + 2 * static_cast<size_t>(idx));
+                spp = *reinterpret_cast<const float2*>(xy2 + 2 * static_cast<size_t>(idx));
+            }
+            __syncthreads();
+            const int npair = len2 >> 1;
+            int p = 0;
+            for (; p + 2 <= npair; p += 2) {
+                const f32x4v u0 = *reinterpret_cast<const f32x4v*>(pts + p * 8);
+                const f32x4v v0 = *reinterpret_cast<const f32x4v*>(pts + p * 8 + 4);
+                const f32x4v u1 = *reinterpret_cast<const f32x4v*>(pts + p * 8 + 8);
+                const f32x4v v1 = *reinterpret_cast<const f32x4v*>(pts + p * 8 + 12);
+                cnt += inlier32_x2<KIND>(f, f32x2{u0[0], u0[1]}, f32x2{u0[2], u0[3]}, f32x2{v0[0], v0[1]}, f32x2{v0[2], v0[3]}, thr2);
+                cnt += inlier32_x2<KIND>(f, f32x2{u1[0], u1[1]}, f32x2{u1[2], u1[3]}, f32x2{v1[0], v1[1]}, f32x2{v1[2], v1[3]}, thr2);
+            }
+            for (; p < npair; ++p) {
+                const f32x4v u0 = *reinterpret_cast<const f32x4v*>(pts + p * 8);
+                const f32x4v v0 = *reinterpret_cast<const f32x4v*>(pts + p * 8 + 4);
+                cnt += inlier32_x2<KIND>(f, f32x2{u0[0], u0[1]}, f32x2{u0[2], u0[3]}, f32x2{v0[0], v0[1]}, f32x2{v0[2], v0[3]}, thr2);
+            }
+            __syncthreads();                        // the stage is rewritten by the next chunk
         }
-        __syncthreads();
-        const int npair = len2 >> 1;
-        int p = 0;
-        for (; p + 2 <= npair; p += 2) {
-            const f32x4v u0 = *reinterpret_cast<const f32x4v*>(pts + p * 8);
-            const f32x4v v0 = *reinterpret_cast<const f32x4v*>(pts + p * 8 + 4);
-            const f32x4v u1 = *reinterpret_cast<const f32x4v*>(pts + p * 8 + 8);
-            const f32x4v v1 = *reinterpret_cast<const f32x4v*>(pts + p * 8 + 12);
-            cnt += inlier32_x2<KIND>(f, f32x2{u0[0], u0[1]}, f32x2{u0[2], u0[3]}, f32x2{v0[0], v0[1]}, f32x2{v0[2], v0[3]}, thr2);
-            cnt += inlier32_x2<KIND>(f, f32x2{u1[0], u1[1]}, f32x2{u1[2], u1[3]}, f32x2{v1[0], v1[1]}, f32x2{v1[2], v1[3]}, thr2);
-        }
-        for (; p < npair; ++p) {
-            const f32x4v u0 = *reinterpret_cast<const f32x4v*>(pts + p * 8);
-            const f32x4v v0 = *reinterpret_cast<const f32x4v*>(pts + p * 8 + 4);
-            cnt += inlier32_x2<KIND>(f, f32x2{u0[0], u0[1]}, f32x2{u0[2], u0[3]}, f32x2{v0[0], v0[1]}, f32x2{v0[2], v0[3]}, thr2);
-        }
-        __syncthreads();                        // the stage is rewritten by the next chunk
     }
     if (t < nh && cnt) atomicAdd(&counts[t], cnt);
     if (!FUSED) return;
@@ -623,6 +691,7 @@ int check_params(const pm_ransac_params* p)
 }
 
 struct ShardScratch {
+    float* pairs;                 // interleaved pair records for the scalar-operand scorer (may be null)
     float* models;
     double* models64;
     int* counts;
@@ -631,23 +700,26 @@ struct ShardScratch {
     FinalOut* fo;
 };
 
-size_t shard_scratch_bytes(const pm_ransac_params* p)
+size_t pairs_bytes(int n_max) { return sizeof(float) * 8 * (static_cast<size_t>(n_max + 1) / 2 + PAIR_PAD); }
+
+size_t shard_scratch_bytes(const pm_ransac_params* p, int n_max)
 {
     const size_t nh = static_cast<size_t>(p->hyp_end - p->hyp_begin);
-    return pm::align_up(sizeof(float) * MODEL_STRIDE * nh, 256) + pm::align_up(sizeof(double) * 9 * nh, 256) +
+    return pm::align_up(pairs_bytes(n_max), 256) + pm::align_up(sizeof(float) * MODEL_STRIDE * nh, 256) + pm::align_up(sizeof(double) * 9 * nh, 256) +
            pm::align_up(sizeof(int) * nh, 256) + pm::align_up(sizeof(int) * (nh / 256 + 2), 256) + 1024;
 }
 
-int take_scratch(pm_ctx* ctx, const pm_ransac_params* p, ShardScratch& sc)
+int take_scratch(pm_ctx* ctx, const pm_ransac_params* p, int n_max, ShardScratch& sc)
 {
     const size_t nh = static_cast<size_t>(p->hyp_end - p->hyp_begin);
+    sc.pairs = static_cast<float*>(pm::arena_take(ctx, pairs_bytes(n_max)));
     sc.models = static_cast<float*>(pm::arena_take(ctx, sizeof(float) * MODEL_STRIDE * nh + 16));
     sc.models64 = static_cast<double*>(pm::arena_take(ctx, sizeof(double) * 9 * nh + 16));
     sc.counts = static_cast<int*>(pm::arena_take(ctx, sizeof(int) * nh + 16));
     sc.n_tickets = static_cast<int>((nh + 255) / 256) + 1;
     sc.tickets = static_cast<int*>(pm::arena_take(ctx, sizeof(int) * (nh / 256 + 2)));
     sc.fo = static_cast<FinalOut*>(pm::arena_take(ctx, sizeof(FinalOut)));
-    PM_REQUIRE(sc.models && sc.models64 && sc.counts && sc.tickets && sc.fo, PM_E_NOMEM, "scratch arena too small");
+    PM_REQUIRE(sc.pairs && sc.models && sc.models64 && sc.counts && sc.tickets && sc.fo, PM_E_NOMEM, "scratch arena too small");
     return PM_OK;
 }
 
@@ -661,13 +733,7 @@ int score_shard(pm_ctx* ctx, const float* dxy1, const float* dxy2, int n, const 
         PM_HIP_CHECK(hipMemsetAsync(d_key, 0, sizeof(unsigned long long), ctx->stream));
         return PM_OK;
     }
-    {
-        pm::ScopedKernelTime t(ctx, "ransac_solve");
-        hipLaunchKernelGGL(ransac_solve, dim3((nh + 63) / 64), dim3(64), 0, ctx->stream, dxy1, dxy2, n, d_n, p->seed,
-                           p->hyp_begin, nh, sc.models, sc.models64, sc.counts, d_key, sc.tickets, sc.n_tickets);
-        PM_HIP_CHECK(hipGetLastError());
-    }
-    // workgroup columns over the correspondences: about 10 workgroups per CU in total, never more
+    // workgroup columns over the correspondences: about 16 workgroups per CU in total, never more
     // columns than minimum-size chunks of the largest possible count
     const int hb = (nh + 255) / 256;
     static const int wgs_per_cu = [] { const char* e = getenv("PM_SCORE_WGS_PER_CU"); return e ? atoi(e) : 16; }();
@@ -677,16 +743,31 @@ int score_shard(pm_ctx* ctx, const float* dxy1, const float* dxy2, int n, const 
     if (chunks > max_chunks) chunks = max_chunks;
     if (chunks < 1) chunks = 1;
     if (chunks > 65535) chunks = 65535;
+    // Large shards (the columns would each loop over several LDS stages) take the scalar-operand
+    // scorer: C4 373 -> 320 us.  Small ones keep the LDS stage: the pair records cost a cold scalar-cache
+    // round trip that a 20 us kernel does not amortise (C3 22.0 vs 23.5 us, C2 14.0 vs 17.0 us).
+    const char* smem_str = getenv("PM_SCORE_SMEM");             // "0"/"1" pins a scorer (tests, A/B timing)
+    const int smem_env = smem_str ? atoi(smem_str) : -1;
+    const bool use_smem = smem_env >= 0 ? smem_env != 0 : static_cast<long long>(chunks) * SCORE_CHUNK < n;
+    {
+        pm::ScopedKernelTime t(ctx, "ransac_solve");
+        hipLaunchKernelGGL(ransac_solve, dim3((nh + 63) / 64), dim3(64), 0, ctx->stream, dxy1, dxy2, n, d_n, p->seed,
+                           p->hyp_begin, nh, sc.models, sc.models64, sc.counts, d_key, sc.tickets, sc.n_tickets,
+                           use_smem ? sc.pairs : nullptr);
+        PM_HIP_CHECK(hipGetLastError());
+    }
     const float thr2 = p->thresh_px * p->thresh_px;
     {
         pm::ScopedKernelTime t(ctx, "ransac_score");
         const FusedTail none{};
         const FusedTail& ft = fused ? *fused : none;
-#define PM_SCORE(KIND_, FUSED_)                                                                                    \
-    hipLaunchKernelGGL((ransac_score<KIND_, FUSED_>), dim3(hb, chunks), dim3(256), 0, ctx->stream, dxy1, dxy2, n, d_n, \
-                       min_chunk, sc.models, nh, thr2, sc.counts, ft)
-        if (p->error_kind == PM_ERR_SAMPSON) { if (fused) PM_SCORE(PM_ERR_SAMPSON, true); else PM_SCORE(PM_ERR_SAMPSON, false); }
-        else { if (fused) PM_SCORE(PM_ERR_SYM_EPIPOLAR, true); else PM_SCORE(PM_ERR_SYM_EPIPOLAR, false); }
+#define PM_SCORE(KIND_, FUSED_, SMEM_)                                                                             \
+    hipLaunchKernelGGL((ransac_score<KIND_, FUSED_, SMEM_>), dim3(hb, chunks), dim3(256), 0, ctx->stream, dxy1, dxy2,  \
+                       sc.pairs, n, d_n, min_chunk, sc.models, nh, thr2, sc.counts, ft)
+#define PM_SCORE2(KIND_, FUSED_) do { if (use_smem) PM_SCORE(KIND_, FUSED_, true); else PM_SCORE(KIND_, FUSED_, false); } while (0)
+        if (p->error_kind == PM_ERR_SAMPSON) { if (fused) PM_SCORE2(PM_ERR_SAMPSON, true); else PM_SCORE2(PM_ERR_SAMPSON, false); }
+        else { if (fused) PM_SCORE2(PM_ERR_SYM_EPIPOLAR, true); else PM_SCORE2(PM_ERR_SYM_EPIPOLAR, false); }
+#undef PM_SCORE2
 #undef PM_SCORE
         PM_HIP_CHECK(hipGetLastError());
     }
@@ -763,7 +844,7 @@ int host_run(pm_ctx* ctx, const float* xy1, const float* xy2, int n, const pm_ra
 
     const size_t xyb = sizeof(float) * 2 * static_cast<size_t>(n);
     const size_t need = 2 * pm::align_up(xyb, 256) + pm::align_up(static_cast<size_t>(n), 256) + 512 +
-                        shard_scratch_bytes(p) + 2048;
+                        shard_scratch_bytes(p, n) + 2048;
     rc = pm::arena_reserve(ctx, need);
     if (rc != PM_OK) return rc;
     pm::arena_reset(ctx);
@@ -773,7 +854,7 @@ int host_run(pm_ctx* ctx, const float* xy1, const float* xy2, int n, const pm_ra
     unsigned long long* dkey = static_cast<unsigned long long*>(pm::arena_take(ctx, 8));
     PM_REQUIRE(dxy1 && dxy2 && dmask && dkey, PM_E_NOMEM, "scratch arena too small");
     ShardScratch sc;
-    rc = take_scratch(ctx, p, sc);
+    rc = take_scratch(ctx, p, n, sc);
     if (rc != PM_OK) return rc;
     rc = pm::pinned_reserve(ctx, sizeof(FinalOut) + 8 + static_cast<size_t>(n));
     if (rc != PM_OK) return rc;
@@ -822,10 +903,10 @@ int dev_prologue(pm_ctx* ctx, const pm_ransac_params* p, int n_max, const float*
     if (rc != PM_OK) return rc;
     PM_REQUIRE(n_max >= 1 && d_xy1 && d_xy2, PM_E_INVALID, "bad point arrays");
     PM_HIP_CHECK(hipSetDevice(ctx->device));
-    rc = pm::arena_reserve(ctx, shard_scratch_bytes(p) + 2048);
+    rc = pm::arena_reserve(ctx, shard_scratch_bytes(p, n_max) + 2048);
     if (rc != PM_OK) return rc;
     pm::arena_reset(ctx);
-    return take_scratch(ctx, p, sc);
+    return take_scratch(ctx, p, n_max, sc);
 }
 
 }  // namespace

@@ -43,6 +43,19 @@ def test_ransac_parity(ctx, oracle, n, iters, out_frac, noise, kind):
         assert min(np.abs(got[1] - Fgt).max(), np.abs(got[1] + Fgt).max()) < 1e-5
 
 
+@pytest.mark.parametrize("n,iters", [(8, 64), (9, 100), (130, 700), (1001, 3000), (2300, 1500)])
+@pytest.mark.parametrize("kind", [PM_ERR_SAMPSON, PM_ERR_SYM_EPIPOLAR])
+def test_ransac_scalar_operand_scorer_same_bits(ctx, oracle, n, iters, kind, monkeypatch):
+    """Both scorers (LDS-staged and scalar-operand pair records; the library picks by shard size)
+    give the oracle's key / mask / F; odd counts exercise the NaN-padded last record."""
+    x1, x2, _, _ = synth.two_view(n, seed=3 * n + iters, outlier_frac=0.3, noise_px=0.5)
+    want = oracle.ransac_fundamental(x1, x2, iters, 1.0, 0x5EED, kind, nthreads=8)
+    for smem in ("1", "0"):
+        monkeypatch.setenv("PM_SCORE_SMEM", smem)
+        _same(ctx.ransac_fundamental(x1, x2, iters, 1.0, 0x5EED, kind), want, str((n, iters, kind, smem)))
+    monkeypatch.delenv("PM_SCORE_SMEM")
+
+
 def test_ransac_every_hypothesis_model_matches(ctx, oracle):
     """model_from_hyp for many ids: sampler + solver + scoring parity per hypothesis."""
     x1, x2, _, _ = synth.two_view(700, seed=77)
