@@ -206,6 +206,27 @@ static inline uint64_t pm_ransac_key(uint32_t inliers, uint32_t hyp) {
 static inline uint32_t pm_ransac_key_hyp(uint64_t key)     { return 0xFFFFFFFFu - (uint32_t)key; }
 static inline uint32_t pm_ransac_key_inliers(uint64_t key) { return (uint32_t)(key >> 32); }
 
+/* ---- 7-point + LMedS: what the reference's call literally selects -----------------
+ * cv::findFundamentalMat(..., CV_FM_7POINT) with more than 7 points runs OpenCV 2.4's least-median
+ * loop over 7-point minimal solves (main.cpp:95-98) [recalled].  Arithmetic: docs/SPEC.md S13-S15.
+ * Hypothesis h in [hyp_begin, hyp_end) samples 7 correspondences and yields up to three models
+ * (ids 3h, 3h+1, 3h+2); the model with the smallest median symmetric-epipolar residual wins (ties
+ * -> lowest id); inliers are the correspondences within the robust sigma derived from that median.
+ * F: row-major, x2^T F x1 = 0, unit Frobenius norm, F[8] >= 0 (pm_f_scale_f33 gives OpenCV's
+ * F[8] = 1).  n <= 32768.  pm_lmeds_default_iters: OpenCV's iteration count
+ * round(log(1 - confidence) / log(1 - (1 - outlier_ratio)^7)) (300 for 0.99 / 0.45). */
+typedef struct pm_lmeds_params {
+    int64_t  hyp_begin, hyp_end;
+    uint64_t seed;
+} pm_lmeds_params;
+int pm_lmeds_fundamental(pm_ctx* ctx, const float* xy1, const float* xy2, int n,
+                         const pm_lmeds_params* p, double F[9], uint8_t* mask, int* n_inliers,
+                         int64_t* best_model, double* median);
+int pm_lmeds_fundamental_dev(pm_ctx* ctx, const float* d_xy1, const float* d_xy2, int n,
+                             const pm_lmeds_params* p, double* d_F, uint8_t* d_mask,
+                             int32_t* d_n_inliers, int64_t* d_best_model, double* d_median);
+int pm_lmeds_default_iters(double confidence, double outlier_ratio);
+
 /* ---- batch of independent image pairs (BASELINE config C5) ----------------------------------
  * One pass of main.cpp:46 -> :49-69 (ratio form) -> :89-91 -> :95-98 per pair, streamed: the batch
  * owns `n_lanes` contexts (stream + scratch + device buffers each); pair j runs on lane

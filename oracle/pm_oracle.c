@@ -480,6 +480,272 @@ int pmo_ransac_model_from_hyp(const float* xy1, const float* xy2, int n, const p
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * SURVEY 8f-3 — the estimator the reference literally calls: findFundamentalMat(..., CV_FM_7POINT)
+ * with more than 7 points runs OpenCV 2.4's LMedS loop over 7-point minimal solves
+ * (main.cpp:95-98) [recalled; OpenCV is absent: parity unpinned, arithmetic frozen by SPEC
+ * S13-S15].
+ * ------------------------------------------------------------------------------------------ */
+/* SPEC S13 — 7 distinct indices, same generator as S6 with a domain-separated stream. */
+void pmo_sample7(uint64_t seed, uint64_t h, int n, int32_t idx[7])
+{
+    uint64_t stream = mix64(seed ^ 0x7F4A7C159E3779B9ULL) ^ mix64(h + 0xD1B54A32D192ED03ULL);
+    int cnt = 0;
+    for (uint64_t d = 0; d < 64 && cnt < 7; ++d) {
+        uint64_t r = mix64(stream + (d + 1) * 0x9E3779B97F4A7C15ULL);
+        int32_t c = (int32_t)(((r >> 32) * (uint64_t)(uint32_t)n) >> 32);
+        int dup = 0;
+        for (int s = 0; s < cnt; ++s) dup |= (idx[s] == c);
+        if (!dup) idx[cnt++] = c;
+    }
+    for (int32_t c = 0; cnt < 7; ++c) {
+        int dup = 0;
+        for (int s = 0; s < cnt; ++s) dup |= (idx[s] == c);
+        if (!dup) idx[cnt++] = c;
+    }
+}
+
+static int hartley7(const double* p, double* pn, double* s_out, double* tx_out, double* ty_out)
+{
+    double cx = p[0], cy = p[1];
+    for (int i = 1; i < 7; ++i) { cx = cx + p[2 * i]; cy = cy + p[2 * i + 1]; }
+    cx = cx / 7.0; cy = cy / 7.0;
+    double md = 0.0;
+    for (int i = 0; i < 7; ++i) {
+        double dx = p[2 * i] - cx, dy = p[2 * i + 1] - cy;
+        md = md + sqrt(fma(dx, dx, dy * dy));
+    }
+    md = md / 7.0;
+    if (!(md > 0.0) || !(md < INFINITY)) return 0;
+    double s = PMO_SQRT2 / md;
+    for (int i = 0; i < 7; ++i) {
+        pn[2 * i] = (p[2 * i] - cx) * s;
+        pn[2 * i + 1] = (p[2 * i + 1] - cy) * s;
+    }
+    *s_out = s; *tx_out = -(s * cx); *ty_out = -(s * cy);
+    return 1;
+}
+
+static double det3(const double* r0, const double* r1, const double* r2)
+{
+    double m0 = r1[1] * r2[2] - r1[2] * r2[1];
+    double m1 = r1[0] * r2[2] - r1[2] * r2[0];
+    double m2 = r1[0] * r2[1] - r1[1] * r2[0];
+    double d = r0[0] * m0;
+    d = d - r0[1] * m1;
+    d = d + r0[2] * m2;
+    return d;
+}
+
+/* SPEC S14 — normalised 7-point solve: up to three models; F[r] (9 doubles each) and valid[r]. */
+int pmo_solve7(const double* p1, const double* p2, double F[27], int valid[3])
+{
+    double n1[14], n2[14], s1, t1x, t1y, s2, t2x, t2y;
+    for (int i = 0; i < 27; ++i) F[i] = 0.0;
+    valid[0] = valid[1] = valid[2] = 0;
+    if (!hartley7(p1, n1, &s1, &t1x, &t1y)) return 0;
+    if (!hartley7(p2, n2, &s2, &t2x, &t2y)) return 0;
+    double B[9][7], beta[7];
+    for (int c = 0; c < 7; ++c) {
+        double x1 = n1[2 * c], y1 = n1[2 * c + 1], x2 = n2[2 * c], y2 = n2[2 * c + 1];
+        B[0][c] = x2 * x1; B[1][c] = x2 * y1; B[2][c] = x2;
+        B[3][c] = y2 * x1; B[4][c] = y2 * y1; B[5][c] = y2;
+        B[6][c] = x1;      B[7][c] = y1;      B[8][c] = 1.0;
+    }
+    for (int j = 0; j < 7; ++j) {
+        double sigma = 0.0;
+        for (int i = j + 1; i < 9; ++i) sigma = fma(B[i][j], B[i][j], sigma);
+        double alpha = B[j][j];
+        double nrm = sqrt(fma(alpha, alpha, sigma));
+        if (!(nrm > 0.0)) { beta[j] = 0.0; continue; }
+        double v0 = alpha + (alpha >= 0.0 ? nrm : -nrm);
+        double vtv = fma(v0, v0, sigma);
+        beta[j] = 2.0 / vtv;
+        B[j][j] = v0;
+        for (int c = j + 1; c < 7; ++c) {
+            double dot = v0 * B[j][c];
+            for (int i = j + 1; i < 9; ++i) dot = fma(B[i][j], B[i][c], dot);
+            double w = beta[j] * dot;
+            B[j][c] = fma(-w, v0, B[j][c]);
+            for (int i = j + 1; i < 9; ++i) B[i][c] = fma(-w, B[i][j], B[i][c]);
+        }
+    }
+    /* null space: g[0] = H0..H6 e7, g[1] = H0..H6 e8 */
+    double g[2][9];
+    for (int v = 0; v < 2; ++v) {
+        for (int i = 0; i < 9; ++i) g[v][i] = 0.0;
+        g[v][7 + v] = 1.0;
+        for (int j = 6; j >= 0; --j) {
+            if (beta[j] == 0.0) continue;
+            double dot = B[j][j] * g[v][j];
+            for (int i = j + 1; i < 9; ++i) dot = fma(B[i][j], g[v][i], dot);
+            double w = beta[j] * dot;
+            g[v][j] = fma(-w, B[j][j], g[v][j]);
+            for (int i = j + 1; i < 9; ++i) g[v][i] = fma(-w, B[i][j], g[v][i]);
+        }
+    }
+    const double *A0 = g[0], *A1 = g[0] + 3, *A2 = g[0] + 6, *B0 = g[1], *B1 = g[1] + 3, *B2 = g[1] + 6;
+    double c3 = det3(A0, A1, A2), c0 = det3(B0, B1, B2);
+    double c2 = det3(B0, A1, A2); c2 = c2 + det3(A0, B1, A2); c2 = c2 + det3(A0, A1, B2);
+    double c1 = det3(A0, B1, B2); c1 = c1 + det3(B0, A1, B2); c1 = c1 + det3(B0, B1, A2);
+    /* det(x*A + y*B) = c3 x^3 + c2 x^2 y + c1 x y^2 + c0 y^3; solve in the better-scaled variable */
+    int swap = !(fabs(c3) >= fabs(c0));
+    double k3 = swap ? c0 : c3, k2 = swap ? c1 : c2, k1 = swap ? c2 : c1, k0 = swap ? c3 : c0;
+    const double* P = swap ? g[1] : g[0];     /* model = z*P + Q */
+    const double* Q = swap ? g[0] : g[1];
+    if (!(fabs(k3) > 0.0)) return 0;
+    double a = k2 / k3, b = k1 / k3, c = k0 / k3;
+    double R = fabs(a); if (fabs(b) > R) R = fabs(b); if (fabs(c) > R) R = fabs(c);
+    R = 1.0 + R;
+    if (!(R < INFINITY)) return 0;
+    double lo = -R, hi = R;
+    for (int it = 0; it < 100; ++it) {
+        double mid = 0.5 * (lo + hi);
+        double v = mid + a; v = fma(v, mid, b); v = fma(v, mid, c);
+        if (v < 0.0) lo = mid; else hi = mid;
+    }
+    double roots[3]; int nr = 1;
+    roots[0] = 0.5 * (lo + hi);
+    double q1 = a + roots[0], q0 = fma(q1, roots[0], b);
+    double disc = fma(q1, q1, -(4.0 * q0));
+    if (disc >= 0.0) {
+        double sq = sqrt(disc);
+        double t = -0.5 * (q1 + (q1 >= 0.0 ? sq : -sq));
+        roots[1] = t;
+        roots[2] = (t != 0.0) ? q0 / t : 0.0;
+        nr = 3;
+    }
+    int any = 0;
+    for (int r = 0; r < nr; ++r) {
+        double z = roots[r], Fn[3][3];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Fn[i][j] = fma(z, P[3 * i + j], Q[3 * i + j]);
+        double M[3][3], Fo[9];
+        for (int i = 0; i < 3; ++i) {
+            M[i][0] = Fn[i][0] * s1;
+            M[i][1] = Fn[i][1] * s1;
+            M[i][2] = fma(Fn[i][0], t1x, fma(Fn[i][1], t1y, Fn[i][2]));
+        }
+        for (int j = 0; j < 3; ++j) {
+            Fo[j] = s2 * M[0][j];
+            Fo[3 + j] = s2 * M[1][j];
+            Fo[6 + j] = fma(t2x, M[0][j], fma(t2y, M[1][j], M[2][j]));
+        }
+        double ss = 0.0;
+        for (int i = 0; i < 9; ++i) ss = fma(Fo[i], Fo[i], ss);
+        double nrm = sqrt(ss);
+        if (!(nrm > 0.0) || !(nrm < INFINITY)) continue;
+        double inv = 1.0 / nrm;
+        if (Fo[8] < 0.0) inv = -inv;
+        for (int i = 0; i < 9; ++i) F[9 * r + i] = Fo[i] * inv;
+        valid[r] = 1; any = 1;
+    }
+    return any;
+}
+
+int pmo_hyp_models7(const float* xy1, const float* xy2, int n, uint64_t seed, uint64_t h, double F[27], int valid[3])
+{
+    int32_t idx[7];
+    double p1[14], p2[14];
+    pmo_sample7(seed, h, n, idx);
+    for (int i = 0; i < 7; ++i) {
+        p1[2 * i] = (double)xy1[2 * idx[i]]; p1[2 * i + 1] = (double)xy1[2 * idx[i] + 1];
+        p2[2 * i] = (double)xy2[2 * idx[i]]; p2[2 * i + 1] = (double)xy2[2 * idx[i] + 1];
+    }
+    return pmo_solve7(p1, p2, F, valid);
+}
+
+/* SPEC S15 — symmetric epipolar residual max(d1^2/|l1|^2, d2^2/|l2|^2), fp64 -> float
+ * (cv CvFMEstimator::computeReprojError [recalled]); NaN counts as +inf. */
+static float lmeds_err(const double* F, float xf, float yf, float xpf, float ypf)
+{
+    double x = (double)xf, y = (double)yf, xp = (double)xpf, yp = (double)ypf;
+    double a = fma(F[0], x, fma(F[1], y, F[2]));
+    double b = fma(F[3], x, fma(F[4], y, F[5]));
+    double c = fma(F[6], x, fma(F[7], y, F[8]));
+    double d2 = fma(xp, a, fma(yp, b, c));
+    double s2 = 1.0 / fma(a, a, b * b);
+    double at = fma(F[0], xp, fma(F[3], yp, F[6]));
+    double bt = fma(F[1], xp, fma(F[4], yp, F[7]));
+    double ct = fma(F[2], xp, fma(F[5], yp, F[8]));
+    double d1 = fma(x, at, fma(y, bt, ct));
+    double s1 = 1.0 / fma(at, at, bt * bt);
+    double e1 = (d1 * d1) * s1, e2 = (d2 * d2) * s2;
+    float e = (float)(e1 >= e2 ? e1 : e2);
+    return (e != e) ? INFINITY : e;
+}
+
+static int cmp_float(const void* a, const void* b)
+{
+    float x = *(const float*)a, y = *(const float*)b;
+    return (x > y) - (x < y);
+}
+
+typedef struct pmo_lmeds_params { int64_t hyp_begin, hyp_end; uint64_t seed; } pmo_lmeds_params;
+
+/* median of the residuals of one model over all n correspondences (as double) */
+double pmo_lmeds_median(const double F[9], const float* xy1, const float* xy2, int n, float* scratch)
+{
+    for (int i = 0; i < n; ++i) scratch[i] = lmeds_err(F, xy1[2 * i], xy1[2 * i + 1], xy2[2 * i], xy2[2 * i + 1]);
+    qsort(scratch, (size_t)n, sizeof(float), cmp_float);
+    return (n & 1) ? (double)scratch[n / 2] : ((double)scratch[n / 2 - 1] + (double)scratch[n / 2]) * 0.5;
+}
+
+int pmo_lmeds_fundamental(const float* xy1, const float* xy2, int n, const pmo_lmeds_params* p, double F[9],
+                          uint8_t* mask, int* n_inliers, int64_t* best_model, double* median_out, int nthreads)
+{
+    if (F) for (int i = 0; i < 9; ++i) F[i] = 0.0;
+    if (mask) memset(mask, 0, (size_t)(n > 0 ? n : 0));
+    if (n_inliers) *n_inliers = 0;
+    if (best_model) *best_model = -1;
+    if (median_out) *median_out = INFINITY;
+    if (n < 8) return -2;
+    if (p->hyp_begin < 0 || p->hyp_end < p->hyp_begin || p->hyp_end > 0x40000000LL) return -1;
+    double best = INFINITY; int64_t best_id = -1; double bestF[9] = {0};
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+#endif
+    {
+        float* scratch = (float*)malloc(sizeof(float) * (size_t)n);
+        double lbest = INFINITY; int64_t lid = -1; double lF[9] = {0};
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+        for (int64_t h = p->hyp_begin; h < p->hyp_end; ++h) {
+            double Fm[27]; int valid[3];
+            if (!pmo_hyp_models7(xy1, xy2, n, p->seed, (uint64_t)h, Fm, valid)) continue;
+            for (int r = 0; r < 3; ++r) {
+                if (!valid[r]) continue;
+                double med = pmo_lmeds_median(Fm + 9 * r, xy1, xy2, n, scratch);
+                int64_t id = 3 * h + r;
+                if (med < lbest || (med == lbest && lid >= 0 && id < lid)) { lbest = med; lid = id; memcpy(lF, Fm + 9 * r, sizeof lF); }
+            }
+        }
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+        { if (lid >= 0 && (lbest < best || (lbest == best && (best_id < 0 || lid < best_id)))) { best = lbest; best_id = lid; memcpy(bestF, lF, sizeof lF); } }
+        free(scratch);
+    }
+    (void)nthreads;
+    if (best_id < 0 || !(best < INFINITY)) return -3;
+    double sigma = ((2.5 * 1.4826) * (1.0 + 5.0 / (double)(n - 7))) * sqrt(best);
+    sigma = sigma > 0.001 ? sigma : 0.001;
+    double thr = sigma * sigma;
+    int cnt = 0;
+    for (int i = 0; i < n; ++i) {
+        float e = lmeds_err(bestF, xy1[2 * i], xy1[2 * i + 1], xy2[2 * i], xy2[2 * i + 1]);
+        int in = (double)e <= thr;
+        if (mask) mask[i] = (uint8_t)in;
+        cnt += in;
+    }
+    if (F) memcpy(F, bestF, sizeof bestF);
+    if (n_inliers) *n_inliers = cnt;
+    if (best_model) *best_model = best_id;
+    if (median_out) *median_out = best;
+    return 0;
+}
+
 /* main.cpp:103-123 — residual report.  transposed != 0 is the reference literally:
  * temp1 = [x1 y1 1] (1x3, main.cpp:110-112), temp2 = [x2 y2 1]^T (main.cpp:113-115),
  * result = temp1 * F * temp2 (main.cpp:117), sum += abs(result) (main.cpp:120). */

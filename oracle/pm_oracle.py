@@ -172,6 +172,49 @@ def ransac_model_from_hyp(xy1, xy2, hyp, thresh_px, seed, kind=0):
     return rc, F.reshape(3, 3), mask[:n], ninl.value
 
 
+class LmedsParams(C.Structure):
+    _fields_ = [("hyp_begin", C.c_int64), ("hyp_end", C.c_int64), ("seed", C.c_uint64)]
+
+
+def lmeds_fundamental(xy1, xy2, iters, seed, hyp_begin=0, nthreads=1):
+    """SPEC S13-S15 (7-point + LMedS).  Returns (status, F(3x3), mask, n_inliers, best_model, median)."""
+    xy1 = np.ascontiguousarray(xy1, np.float32)
+    xy2 = np.ascontiguousarray(xy2, np.float32)
+    n = xy1.shape[0]
+    prm = LmedsParams(hyp_begin, iters, seed)
+    F = np.zeros(9, np.float64)
+    mask = np.zeros(max(n, 1), np.uint8)
+    ninl, best, med = C.c_int(), C.c_int64(), C.c_double()
+    rc = lib().pmo_lmeds_fundamental(_p(xy1), _p(xy2), n, C.byref(prm), _p(F), _p(mask), C.byref(ninl),
+                                     C.byref(best), C.byref(med), nthreads)
+    return rc, F.reshape(3, 3), mask[:n], ninl.value, best.value, med.value
+
+
+def sample7(seed, h, n):
+    idx = np.zeros(7, np.int32)
+    lib().pmo_sample7(C.c_uint64(seed), C.c_uint64(h), n, _p(idx))
+    return idx
+
+
+def solve7(p1, p2):
+    """p1, p2: 7x2 float64.  Returns (F (3,3,3), valid (3,))."""
+    p1 = np.ascontiguousarray(p1, np.float64)
+    p2 = np.ascontiguousarray(p2, np.float64)
+    F = np.zeros(27, np.float64)
+    valid = np.zeros(3, np.int32)
+    lib().pmo_solve7(_p(p1), _p(p2), _p(F), _p(valid))
+    return F.reshape(3, 3, 3), valid
+
+
+def lmeds_median(F, xy1, xy2):
+    xy1 = np.ascontiguousarray(xy1, np.float32)
+    xy2 = np.ascontiguousarray(xy2, np.float32)
+    F = np.ascontiguousarray(F, np.float64).reshape(9)
+    scratch = np.zeros(xy1.shape[0], np.float32)
+    lib().pmo_lmeds_median.restype = C.c_double
+    return lib().pmo_lmeds_median(_p(F), _p(xy1), _p(xy2), xy1.shape[0], _p(scratch)), scratch
+
+
 def epipolar_residuals(xy1, xy2, F, transposed=1):
     xy1 = np.ascontiguousarray(xy1, np.float32)
     xy2 = np.ascontiguousarray(xy2, np.float32)

@@ -36,6 +36,7 @@ EXPORTS = [
     "pm_ransac_fundamental", "pm_ransac_score_dev", "pm_ransac_score_devn", "pm_ransac_model_from_hyp",
     "pm_ransac_model_from_key_dev", "pm_ransac_run_dev",
     "pm_batch_create", "pm_batch_destroy", "pm_batch_run", "pm_host_register", "pm_host_unregister",
+    "pm_lmeds_fundamental", "pm_lmeds_fundamental_dev", "pm_lmeds_default_iters",
     "pm_epipolar_residuals", "pm_f_scale_f33", "pm_epilines", "pm_epiline_endpoints",
 ]
 
@@ -324,6 +325,30 @@ class Context:
         prm = RansacParams(hyp_begin, hyp_end, seed, thresh_px, kind)
         _check(lib().pm_ransac_score_dev(self._h, C.c_void_p(dxy1_ptr), C.c_void_p(dxy2_ptr), n,
                                          C.byref(prm), C.c_void_p(dkey_ptr)))
+
+
+class LmedsParams(C.Structure):
+    _fields_ = [("hyp_begin", C.c_int64), ("hyp_end", C.c_int64), ("seed", C.c_uint64)]
+
+
+def lmeds_default_iters(confidence=0.99, outlier_ratio=0.45):
+    return lib().pm_lmeds_default_iters(C.c_double(confidence), C.c_double(outlier_ratio))
+
+
+def lmeds_fundamental(ctx, xy1, xy2, iters, seed, hyp_begin=0):
+    """7-point + LMedS (SPEC S13-S15).  Returns (status, F(3x3), mask, n_inliers, best_model, median)."""
+    xy1 = np.ascontiguousarray(xy1, np.float32).reshape(-1, 2)
+    xy2 = np.ascontiguousarray(xy2, np.float32).reshape(-1, 2)
+    n = xy1.shape[0]
+    prm = LmedsParams(hyp_begin, iters, seed)
+    F = np.zeros(9, np.float64)
+    mask = np.zeros(max(n, 1), np.uint8)
+    ninl, best, med = C.c_int(), C.c_int64(), C.c_double()
+    rc = lib().pm_lmeds_fundamental(ctx._h, _p(xy1), _p(xy2), n, C.byref(prm), _p(F), _p(mask), C.byref(ninl),
+                                    C.byref(best), C.byref(med))
+    if rc not in (PM_OK, PM_E_NO_MODEL, PM_E_TOO_FEW):
+        _check(rc)
+    return rc, F.reshape(3, 3), mask[:n], ninl.value, best.value, med.value
 
 
 # ---- batch of image pairs (BASELINE config C5) ---------------------------------------------------

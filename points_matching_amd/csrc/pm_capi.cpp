@@ -411,3 +411,16 @@ int pm_epiline_endpoints(const float* lines, int n, int cols, int32_t* xyxy)
 }
 
 }  // extern "C"
+
+/* OpenCV 2.4 CvModelEstimator2::runLMeDS iteration count [recalled]: 300 for (0.99, 0.45). */
+extern "C" int pm_lmeds_default_iters(double confidence, double outlier_ratio)
+{
+    if (!(confidence > 0.0) || !(confidence < 1.0) || !(outlier_ratio >= 0.0) || !(outlier_ratio < 1.0)) return -1;
+    const double w7 = std::pow(1.0 - outlier_ratio, 7.0);
+    const double den = std::log(1.0 - w7);
+    if (!(den < 0.0)) return 1;
+    const double it = std::log(1.0 - confidence) / den;
+    if (!(it < 1e9)) return 1000000000;
+    const long r = std::lround(it);
+    return static_cast<int>(r < 1 ? 1 : r);
+}

@@ -51,8 +51,31 @@ def main():
         samples = np.stack([O.sample8(0x5EED, h, 512) for h in range(16)])
         np.savez_compressed(os.path.join(HERE, "twoview_N512_%s.npz" % name), xy1=x1, xy2=x2, F_gt=Fgt,
                             gt_inlier=inl, samples_h0_15=samples, **res)
+    lmeds()
     print("golden fixtures written to", HERE)
 
 
+def lmeds():
+    """7-point + LMedS (SPEC S13-S15) answers on the two-view fixtures' own point sets."""
+    res = {}
+    for name, out_frac, noise in (("clean", 0.0, 0.0), ("noisy", 0.0, 0.5), ("outliers", 0.35, 0.5)):
+        x1, x2, Fgt, inl = synth.two_view(512, seed=0x6021, outlier_frac=out_frac, noise_px=noise)
+        rc, F, mask, n, best, med = O.lmeds_fundamental(x1, x2, 300, 0x7EED)
+        assert rc == 0
+        res["F_bits_" + name] = F.reshape(9).view(np.uint64)
+        res["mask_" + name] = mask
+        res["best_" + name] = np.array([best], np.int64)
+        res["median_bits_" + name] = np.array([med], np.float64).view(np.uint64)
+    x1, x2, _, _ = synth.two_view(64, seed=0x6022)
+    p1 = x1[:7].astype(np.float64)
+    p2 = x2[:7].astype(np.float64)
+    F7, valid = O.solve7(p1, p2)
+    np.savez_compressed(os.path.join(HERE, "lmeds_N512.npz"), solve7_p1=p1, solve7_p2=p2,
+                        solve7_F_bits=F7.reshape(27).view(np.uint64), solve7_valid=valid, **res)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "lmeds":
+        lmeds()
+    else:
+        main()

@@ -20,7 +20,7 @@ def _knn_cases():
 
 
 def test_fixtures_present():
-    assert len(glob.glob(os.path.join(GOLD, "*.npz"))) == 8
+    assert len(glob.glob(os.path.join(GOLD, "*.npz"))) == 9
 
 
 @pytest.mark.parametrize("name,k", _knn_cases())
@@ -50,6 +50,30 @@ def test_oracle_reproduces_twoview(oracle, name):
         assert g["mask_0"].all()
         F = g["F_bits_0"].view(np.float64).reshape(3, 3)
         assert min(np.abs(F - g["F_gt"]).max(), np.abs(F + g["F_gt"]).max()) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["clean", "noisy", "outliers"])
+def test_oracle_reproduces_lmeds(oracle, name):
+    g, tv = _load("lmeds_N512.npz"), _load("twoview_N512_%s.npz" % name)
+    rc, F, mask, n, best, med = oracle.lmeds_fundamental(tv["xy1"], tv["xy2"], 300, 0x7EED, nthreads=4)
+    assert rc == 0 and best == int(g["best_" + name][0])
+    assert np.float64(med).view(np.uint64) == g["median_bits_" + name][0]
+    assert (F.reshape(9).view(np.uint64) == g["F_bits_" + name]).all() and (mask == g["mask_" + name]).all()
+    if name == "clean":
+        assert mask.all() and min(np.abs(F - tv["F_gt"]).max(), np.abs(F + tv["F_gt"]).max()) < 1e-5
+    F7, valid = oracle.solve7(g["solve7_p1"], g["solve7_p2"])
+    assert (valid == g["solve7_valid"]).all() and (F7.reshape(27).view(np.uint64) == g["solve7_F_bits"]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["clean", "noisy", "outliers"])
+def test_hip_reproduces_lmeds(ctx, name):
+    from points_matching_amd.api import lmeds_fundamental
+    g, tv = _load("lmeds_N512.npz"), _load("twoview_N512_%s.npz" % name)
+    rc, F, mask, n, best, med = lmeds_fundamental(ctx, tv["xy1"], tv["xy2"], 300, 0x7EED)
+    assert rc == 0 and best == int(g["best_" + name][0])
+    assert np.float64(med).view(np.uint64) == g["median_bits_" + name][0]
+    assert (F.reshape(9).view(np.uint64) == g["F_bits_" + name]).all() and (mask == g["mask_" + name]).all()
 
 
 @pytest.mark.gpu

@@ -237,3 +237,43 @@ def test_epilines_and_endpoints(oracle):
     for i in range(20):
         a, b, c = l[i]
         assert e[i, 1] == int(np.trunc(-c / b)) and e[i, 3] == int(np.trunc(-(c + a * f32(993)) / b))
+
+
+# ---- 7-point + LMedS (SPEC S13-S15) ----------------------------------------------------------------
+def test_solve7_models_satisfy_the_sample_and_are_singular(oracle):
+    from points_matching_amd import synth
+    x1, x2, Fgt, _ = synth.two_view(300, seed=9, outlier_frac=0.0, noise_px=0.0)
+    rng = np.random.default_rng(1)
+    hit = 0
+    for trial in range(20):
+        idx = rng.permutation(300)[:7]
+        p1, p2 = x1[idx].astype(np.float64), x2[idx].astype(np.float64)
+        F, valid = oracle.solve7(p1, p2)
+        assert valid[0] == 1                          # a real cubic always has a real root
+        for r in range(3):
+            if not valid[r]:
+                continue
+            Fr = F[r]
+            assert abs(np.linalg.norm(Fr) - 1.0) < 1e-12 and Fr[2, 2] >= 0
+            h1 = np.c_[p1, np.ones(7)]
+            h2 = np.c_[p2, np.ones(7)]
+            assert np.abs(np.einsum("ni,ij,nj->n", h2, Fr, h1)).max() < 1e-9        # x2^T F x1 = 0 on the sample
+            assert abs(np.linalg.det(Fr)) < 1e-12                                   # rank 2 by construction
+            hit += min(np.abs(Fr - Fgt).max(), np.abs(Fr + Fgt).max()) < 1e-5
+    assert hit >= 20                                  # noiseless data: one of the roots is the true F
+
+
+def test_lmeds_recovers_f_and_is_thread_independent(oracle):
+    from points_matching_amd import synth
+    x1, x2, Fgt, inl = synth.two_view(800, seed=12, outlier_frac=0.3, noise_px=0.5)
+    a = oracle.lmeds_fundamental(x1, x2, 300, 3, nthreads=1)
+    b = oracle.lmeds_fundamental(x1, x2, 300, 3, nthreads=8)
+    assert a[0] == b[0] == 0 and a[4] == b[4] and a[5] == b[5] and (a[2] == b[2]).all()
+    assert (a[1].view(np.uint64) == b[1].view(np.uint64)).all()
+    assert (a[2].astype(bool) == inl).mean() > 0.97
+    # the winner's median equals an independent numpy median of the same residuals
+    med, errs = oracle.lmeds_median(a[1], x1, x2)
+    assert med == a[5] and med == float(np.median(np.sort(errs).astype(np.float64)))
+    assert oracle.lmeds_fundamental(x1[:7], x2[:7], 10, 1)[0] == -2
+    s = [tuple(oracle.sample7(5, h, 100)) for h in range(50)]
+    assert all(len(set(t)) == 7 and min(t) >= 0 and max(t) < 100 for t in s) and len(set(s)) == 50
