@@ -280,28 +280,37 @@ __device__ __forceinline__ float lmeds_err(const double (&F)[9], float2 p, float
 }
 
 // rank-th smallest (0-based) of the n non-negative float keys in LDS: MSB-first radix select, 8 bits
-// per pass.  hist[256] + ctl[2] are LDS scratch.  All threads of the workgroup call it.
+// per pass.  hist[256], wsum[4] and ctl[2] are LDS scratch.  All 256 threads of the workgroup call
+// it; thread b owns histogram bin b (block-wide exclusive scan: wave shuffles + 4 wave totals).
 __device__ __forceinline__ uint32_t radix_select(const uint32_t* __restrict__ keys, int n, int rank, uint32_t* hist,
-                                                 uint32_t* ctl)
+                                                 uint32_t* wsum, uint32_t* ctl)
 {
     uint32_t prefix = 0u, mask = 0u;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int pass = 3; pass >= 0; --pass) {
         const int sh = 8 * pass;
-        hist[threadIdx.x] = 0u;                       // 256 threads, 256 bins
+        hist[threadIdx.x] = 0u;
         __syncthreads();
         for (int i = threadIdx.x; i < n; i += 256) {
             const uint32_t k = keys[i];
             if ((k & mask) == prefix) atomicAdd(&hist[(k >> sh) & 255u], 1u);
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t acc = 0u, bin = 255u, before = 0u;
-            for (uint32_t b = 0; b < 256u; ++b) {
-                const uint32_t h = hist[b];
-                if (acc + h > static_cast<uint32_t>(rank)) { bin = b; before = acc; break; }
-                acc += h;
-            }
-            ctl[0] = bin;
+        const uint32_t h = hist[threadIdx.x];
+        uint32_t inc = h;                              // inclusive scan inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += v;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t base = 0u;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) base += (w < wave) ? wsum[w] : 0u;
+        const uint32_t before = base + inc - h;        // keys in lower bins
+        if (static_cast<uint32_t>(rank) >= before && static_cast<uint32_t>(rank) < before + h) {   // exactly one bin
+            ctl[0] = threadIdx.x;
             ctl[1] = before;
         }
         __syncthreads();
@@ -317,10 +326,11 @@ __global__ __launch_bounds__(256) void lmeds_median(const float* __restrict__ xy
                                                     const double* __restrict__ models, const int* __restrict__ mvalid,
                                                     double* __restrict__ meds)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lm_lds[];     // [n] keys, [256] hist, [2] ctl
+    extern __shared__ __attribute__((aligned(16))) uint32_t lm_lds[];     // [n] keys, [256] hist, [4] wsum, [2] ctl
     uint32_t* keys = lm_lds;
     uint32_t* hist = lm_lds + n;
-    uint32_t* ctl = hist + 256;
+    uint32_t* wsum = hist + 256;
+    uint32_t* ctl = wsum + 4;
     const int model = blockIdx.x;
     if (!mvalid[model]) {                              // uniform
         if (threadIdx.x == 0) meds[model] = LM_INF;
@@ -335,10 +345,21 @@ __global__ __launch_bounds__(256) void lmeds_median(const float* __restrict__ xy
         keys[i] = __float_as_uint(lmeds_err(F, p, pp));        // >= +0: the bit pattern orders like the value
     }
     __syncthreads();
-    const uint32_t hi = radix_select(keys, n, n / 2, hist, ctl);
+    const uint32_t hi = radix_select(keys, n, n / 2, hist, wsum, ctl);
     double med = static_cast<double>(__uint_as_float(hi));
     if ((n & 1) == 0) {
-        const uint32_t lo = radix_select(keys, n, n / 2 - 1, hist, ctl);
+        // v[n/2 - 1] in one more pass: with L = #keys strictly below v[n/2] (L <= n/2), it is the largest
+        // of those keys when L == n/2, and v[n/2] itself (a duplicate) when L < n/2
+        if (threadIdx.x < 2) ctl[threadIdx.x] = 0u;
+        __syncthreads();
+        uint32_t less = 0u, mx = 0u;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const uint32_t k = keys[i];
+            if (k < hi) { ++less; mx = k > mx ? k : mx; }
+        }
+        if (less) { atomicAdd(&ctl[0], less); atomicMax(&ctl[1], mx); }
+        __syncthreads();
+        const uint32_t lo = ctl[0] >= static_cast<uint32_t>(n / 2) ? ctl[1] : hi;
         med = (static_cast<double>(__uint_as_float(lo)) + med) * 0.5;
     }
     if (threadIdx.x == 0) meds[model] = med;
@@ -455,7 +476,7 @@ int run_lmeds(pm_ctx* ctx, const float* dxy1, const float* dxy2, int n, const pm
                                p->hyp_begin, nh, models, mvalid);
             PM_HIP_CHECK(hipGetLastError());
         }
-        const size_t lds = sizeof(uint32_t) * (static_cast<size_t>(n) + 256 + 2);
+        const size_t lds = sizeof(uint32_t) * (static_cast<size_t>(n) + 256 + 4 + 2);
         static size_t lds_set = 0;
         if (lds > lds_set) {
             PM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lmeds_median),

@@ -6,7 +6,9 @@
 //
 //   pm_cli --desc1 a.pmm --desc2 b.pmm --kp1 ka.pmm --kp2 kb.pmm
 //          [--filter midpoint|ratio] [--ratio 0.8] [--iters 10000] [--thresh 1.0] [--seed 24301]
-//          [--f-scale opencv|unit] [--device 0] [--quiet] [--json]
+//          [--method ransac8|7point-lmeds] [--f-scale opencv|unit] [--device 0] [--quiet] [--json]
+// --method 7point-lmeds is the estimator the reference's CV_FM_7POINT call literally selects (7-point
+// solver inside the LMedS loop; --iters defaults to OpenCV's 300 then); ransac8 is BASELINE's.
 //
 // .pmm file: magic "PMM1", int32 rows, int32 cols, int32 dtype (0 = float32, 1 = uint8), data
 // row-major.  float32 descriptors -> BF-L2 (main.cpp:43), uint8 -> BF-Hamming.
@@ -60,12 +62,12 @@ int fail(const char* what, int rc)
 
 int main(int argc, char** argv)
 {
-    std::string desc1, desc2, kp1, kp2, filter = "midpoint", fscale = "opencv";
+    std::string desc1, desc2, kp1, kp2, filter = "midpoint", fscale = "opencv", method = "ransac8";
     float ratio = 0.8f, thresh = 1.0f;
     long iters = 10000;
     unsigned long long seed = 0x5EED;
     int device = 0;
-    bool quiet = false, json = false;
+    bool quiet = false, json = false, iters_given = false;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto val = [&](const char* name) -> const char* {
@@ -78,10 +80,11 @@ int main(int argc, char** argv)
         else if (a == "--kp2") kp2 = val("--kp2");
         else if (a == "--filter") filter = val("--filter");
         else if (a == "--ratio") ratio = strtof(val("--ratio"), nullptr);
-        else if (a == "--iters") iters = strtol(val("--iters"), nullptr, 0);
+        else if (a == "--iters") { iters = strtol(val("--iters"), nullptr, 0); iters_given = true; }
         else if (a == "--thresh") thresh = strtof(val("--thresh"), nullptr);
         else if (a == "--seed") seed = strtoull(val("--seed"), nullptr, 0);
         else if (a == "--f-scale") fscale = val("--f-scale");
+        else if (a == "--method") method = val("--method");
         else if (a == "--device") device = atoi(val("--device"));
         else if (a == "--quiet") quiet = true;
         else if (a == "--json") json = true;
@@ -100,6 +103,7 @@ int main(int argc, char** argv)
         return 1;
     }
     const bool want_ratio = filter == "ratio";
+    if (method != "ransac8" && method != "7point-lmeds") { fprintf(stderr, "pm_cli: --method ransac8|7point-lmeds\n"); return 2; }
     if (!want_ratio && filter != "midpoint") { fprintf(stderr, "pm_cli: --filter midpoint|ratio\n"); return 2; }
 
     pm_ctx* ctx = nullptr;
@@ -160,10 +164,21 @@ int main(int argc, char** argv)
     std::vector<uint8_t> mask(static_cast<size_t>(n_good) + 1);
     int n_inl = 0;
     uint64_t key = 0;
+    long long lmeds_model = -1;
     pm_ransac_params prm;
     prm.hyp_begin = 0; prm.hyp_end = iters; prm.seed = seed; prm.thresh_px = thresh; prm.error_kind = PM_ERR_SAMPSON;
-    rc = pm_ransac_fundamental(ctx, xy1.data(), xy2.data(), n_good, &prm, F, mask.data(), &n_inl, &key);
-    if (rc != PM_OK && rc != PM_E_TOO_FEW && rc != PM_E_NO_MODEL) return fail("pm_ransac_fundamental", rc);
+    if (method == "7point-lmeds") {
+        pm_lmeds_params lp;
+        lp.hyp_begin = 0; lp.hyp_end = iters_given ? iters : pm_lmeds_default_iters(0.99, 0.45); lp.seed = seed;
+        int64_t best_model = -1;
+        double median = 0;
+        rc = pm_lmeds_fundamental(ctx, xy1.data(), xy2.data(), n_good, &lp, F, mask.data(), &n_inl, &best_model, &median);
+        lmeds_model = best_model;
+        if (rc != PM_OK && rc != PM_E_TOO_FEW && rc != PM_E_NO_MODEL) return fail("pm_lmeds_fundamental", rc);
+    } else {
+        rc = pm_ransac_fundamental(ctx, xy1.data(), xy2.data(), n_good, &prm, F, mask.data(), &n_inl, &key);
+        if (rc != PM_OK && rc != PM_E_TOO_FEW && rc != PM_E_NO_MODEL) return fail("pm_ransac_fundamental", rc);
+    }
     // like cv::findFundamentalMat, a failed estimate yields the zero matrix
     const auto t3 = clk::now();
     if (fscale == "opencv") pm_f_scale_f33(F);
@@ -185,7 +200,8 @@ int main(int argc, char** argv)
                "\"ransac_status\": %d, \"mean_abs_x1Fx2\": %.17g, \"mean_abs_x2Fx1\": %.17g, "
                "\"ms\": {\"match\": %.3f, \"filter_gather\": %.3f, \"ransac\": %.3f}, "
                "\"F\": [%.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g]}\n",
-               d1.rows, d2.rows, d1.cols, n_good, n_inl, key ? pm_ransac_key_hyp(key) : 0u, rc == PM_OK ? 0 : rc,
+               d1.rows, d2.rows, d1.cols, n_good, n_inl,
+               method == "7point-lmeds" ? lmeds_model : static_cast<long long>(key ? pm_ransac_key_hyp(key) : 0u), rc == PM_OK ? 0 : rc,
                mean_abs, mean_fwd, ms(t0, t1), ms(t1, t2), ms(t2, t3), F[0], F[1], F[2], F[3], F[4], F[5], F[6],
                F[7], F[8]);
     }

@@ -52,3 +52,25 @@ def test_cli_stdout_matches_reference_format(tmp_path, oracle, mode):
     assert js["matches"] == good.size and js["inliers"] == ninl
     assert js["best_hyp"] == 0xFFFFFFFF - (key & 0xFFFFFFFF)
     assert np.array_equal(np.array(js["F"]), F.reshape(9))
+
+
+def test_cli_7point_lmeds_method(tmp_path, oracle):
+    """--method 7point-lmeds: what the reference's CV_FM_7POINT call selects (main.cpp:95-98);
+    default iteration count = OpenCV's 300."""
+    exe = build.HOST_BIN
+    w = synth.pair_workload(nq=400, nt=380, dim=128, seed=78, planted=0.5, kind="sift")
+    paths = {}
+    for name in ("q", "t", "kp1", "kp2"):
+        paths[name] = str(tmp_path / (name + ".pmm"))
+        io.save_pmm(paths[name], w[name])
+    cmd = [exe, "--desc1", paths["q"], "--desc2", paths["t"], "--kp1", paths["kp1"], "--kp2", paths["kp2"],
+           "--filter", "ratio", "--method", "7point-lmeds", "--seed", "5", "--json", "--quiet"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    js = json.loads(out.stdout.splitlines()[-1])
+    good = oracle.filter_ratio(oracle.bf_knn_l2(w["q"], w["t"], 2), 0.8)
+    xy1 = oracle.gather_points(w["kp1"], good["queryIdx"])
+    xy2 = oracle.gather_points(w["kp2"], good["trainIdx"])
+    rc, F, mask, ninl, best, med = oracle.lmeds_fundamental(xy1, xy2, 300, 5, nthreads=4)
+    assert rc == 0 and js["matches"] == good.size and js["inliers"] == ninl and js["best_hyp"] == best
+    assert np.array_equal(np.array(js["F"]), oracle.f_scale_f33(F).reshape(9))
