@@ -384,8 +384,8 @@ def main():
                            "traffic": pmc_traffic("c4:knn_hamming_mfma_i8", nq, nt),
                            "algorithmic_bytes": (nq + nt) * dim + nq * K * 16,
                            "dtype": "i8 (+-1 expanded bits) x i8 -> i32 MFMA; exact",
-                           "note": "the kernel issues 9 k-chunks per 8 data chunks (pad-row seed): 12.5% of the "
-                                   "issued MFMAs are not algorithmic work"}
+                           "note": "VALU-issue bound next to the matrix pipe: grouped (8-row) top-4 selection, 1.1 VALU ops "
+                                   "per pair; every issued MFMA is algorithmic work (no seed chunk)"}
     elif hamming and "knn_hamming" in kern:
         # 16 integer VALU ops per pair (8 x v_xor_b32 + 8 x v_bcnt_u32_b32 at 32 B); one wave64 VALU
         # instruction occupies its SIMD 4 cycles: 1024 SIMDs * 64 lanes * 2.4 GHz / 4 = 3.93e13 lane-ops/s

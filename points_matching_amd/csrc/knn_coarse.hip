@@ -290,6 +290,10 @@ __global__ __launch_bounds__(256, (TT == 64 ? 2 : 1)) void knn_l2_mfma(
 //             values int, candidate = (dot << I8_SHIFT) | group id.
 // `par` is the f16 route's keep mask (unused by the i8 route: its shift is a constant).
 struct RouteF16 {
+    static constexpr int NCH = H_NCH;                 // 8 data chunks + the seed chunk
+    static constexpr int ROW16 = H_ROW16;             // 16-byte units per global row
+    static constexpr int LDS_ROW16 = H_LDS_ROW16;     // ... per LDS row (one pad slot)
+    static constexpr int GPB = 4;                     // row groups per 32-row block and lane: groups of 4 rows
     typedef f16x8 frag;
     typedef f32x16 acc;
     typedef f32x4 list;
@@ -309,6 +313,10 @@ struct RouteF16 {
 };
 
 struct RouteI8 {
+    static constexpr int NCH = I8_NCH;                // 8 data chunks, no seed: pad rows are all-zero (dot = 0)
+    static constexpr int ROW16 = I8_ROW16;
+    static constexpr int LDS_ROW16 = I8_LDS_ROW16;
+    static constexpr int GPB = 2;                     // groups of 8 rows: the popcount refinement is cheap
     typedef i32x4 frag;
     typedef i32x16 acc;
     typedef i32x4 list;
@@ -321,7 +329,9 @@ struct RouteI8 {
     static __device__ __forceinline__ int med3(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }
     static __device__ __forceinline__ void select(const acc& a, unsigned par, unsigned gid, list& cl, int g)
     {
-        const int m = max(max(max(a[4 * g], a[4 * g + 1]), a[4 * g + 2]), a[4 * g + 3]);
+        const int m0 = max(max(a[8 * g], a[8 * g + 1]), a[8 * g + 2]);              // v_max3_i32 x3 + v_max_i32
+        const int m1 = max(max(a[8 * g + 3], a[8 * g + 4]), a[8 * g + 5]);
+        const int m = max(max(max(m0, m1), a[8 * g + 6]), a[8 * g + 7]);
         const int x = static_cast<int>((static_cast<unsigned>(m) << I8_SHIFT) | gid);   // v_lshl_or_b32
         (void)par;
         const int n0 = max(x, cl[0]);
@@ -332,10 +342,10 @@ struct RouteI8 {
     }
 };
 
-// a tile = 128 rows x 288 B = 2304 x 16 B, staged through registers by THREADS threads
-template <int THREADS>
+// a tile = 128 rows x R::ROW16 16-byte units, staged through registers by THREADS threads
+template <typename R, int THREADS>
 struct HTile {
-    static constexpr int TOTAL = H_TT * H_ROW16;
+    static constexpr int TOTAL = H_TT * R::ROW16;
     static constexpr int PIECES = (TOTAL + THREADS - 1) / THREADS;
     static constexpr bool EVEN = TOTAL % THREADS == 0;
     uint4 stg[PIECES];
@@ -353,8 +363,8 @@ struct HTile {
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
             const int f = tid + THREADS * i;
-            const int row = f / H_ROW16, c8 = f % H_ROW16;
-            if (EVEN || f < TOTAL) hsm[(buf * H_TT + row) * H_LDS_ROW16 + c8] = stg[i];
+            const int row = f / R::ROW16, c8 = f % R::ROW16;
+            if (EVEN || f < TOTAL) hsm[(buf * H_TT + row) * R::LDS_ROW16 + c8] = stg[i];
         }
     }
 };
@@ -363,7 +373,7 @@ struct HTile {
 // block's accumulators p[] (group-id base pbase) in between, from chunk 1 on (see knn_tile_compute).
 // tb: this lane's row in the LDS tile, in 16-byte units (chunk c = tb[2*c])
 template <typename R, int NQB, bool EPI>
-__device__ __forceinline__ void h_block(const uint4* __restrict__ tb, const typename R::frag (&qf)[NQB][H_NCH],
+__device__ __forceinline__ void h_block(const uint4* __restrict__ tb, const typename R::frag (&qf)[NQB][R::NCH],
                                         typename R::acc (&a)[NQB], const typename R::acc (&p)[NQB], unsigned pbase,
                                         unsigned par, typename R::list (&cl)[NQB])
 {
@@ -374,15 +384,15 @@ __device__ __forceinline__ void h_block(const uint4* __restrict__ tb, const type
 #pragma unroll
     for (int c = 0; c < 3; ++c) ring[c] = *reinterpret_cast<const frag*>(tb + 2 * c);
 #pragma unroll
-    for (int c = 0; c < H_NCH; ++c) {
+    for (int c = 0; c < R::NCH; ++c) {
         const frag x = ring[c % 3];
-        if (c + 3 < H_NCH) ring[c % 3] = *reinterpret_cast<const frag*>(tb + 2 * (c + 3));
+        if (c + 3 < R::NCH) ring[c % 3] = *reinterpret_cast<const frag*>(tb + 2 * (c + 3));
 #pragma unroll
         for (int qb = 0; qb < NQB; ++qb) a[qb] = R::mfma(x, qf[qb][c], c == 0 ? R::zero() : a[qb]);
-        if (EPI && c >= 1) {                      // 4*NQB row groups over chunks 1..8
-            constexpr int NGB = 4 * NQB;
+        if (EPI && c >= 1) {                      // GPB*NQB row groups spread over chunks 1..NCH-1
+            constexpr int NGB = R::GPB * NQB;
 #pragma unroll
-            for (int e = (c - 1) * NGB / 8; e < c * NGB / 8; ++e)       // query column e % NQB, group e / NQB
+            for (int e = (c - 1) * NGB / (R::NCH - 1); e < c * NGB / (R::NCH - 1); ++e)   // query column e % NQB, group e / NQB
                 R::select(p[e % NQB], par, pbase + static_cast<unsigned>(e / NQB), cl[e % NQB], e / NQB);
             if (NQB == 2)
                 asm volatile("" : "+v"(cl[0][0]), "+v"(cl[0][1]), "+v"(cl[0][2]), "+v"(cl[0][3]), "+v"(cl[NQB - 1][0]),
@@ -411,23 +421,23 @@ __global__ __launch_bounds__(H_QB / (32 * NQB) * 64, (NQB == 2 ? 2 : 4)) void kn
         const unsigned long long s1 = stats[1];
         if (static_cast<unsigned>(s1 >> 32) == epoch && (s1 & 2ull)) return;      // f32 route takes over
     }
-    extern __shared__ __attribute__((aligned(16))) uint4 hsm[];                   // [2][H_TT][H_LDS_ROW16]
+    extern __shared__ __attribute__((aligned(16))) uint4 hsm[];                   // [2][H_TT][R::LDS_ROW16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int qbase = blockIdx.x * H_QB + wave * 32 * NQB;
 
-    frag qf[NQB][H_NCH];
+    frag qf[NQB][R::NCH];
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
-        for (int c = 0; c < H_NCH; ++c)
-            qf[qb][c] = *reinterpret_cast<const frag*>(Qh + static_cast<size_t>(qbase + 32 * qb + r) * H_ROW16 + 2 * c + h);
+        for (int c = 0; c < R::NCH; ++c)
+            qf[qb][c] = *reinterpret_cast<const frag*>(Qh + static_cast<size_t>(qbase + 32 * qb + r) * R::ROW16 + 2 * c + h);
     // make the fragments opaque: hipcc otherwise treats the loads as rematerialisable and re-reads
     // some of them from global memory inside the tile loop
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
-        for (int c = 0; c < H_NCH; ++c) {
+        for (int c = 0; c < R::NCH; ++c) {
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             u32x4 t = __builtin_bit_cast(u32x4, qf[qb][c]);
             asm volatile("" : "+v"(t));
@@ -442,7 +452,7 @@ __global__ __launch_bounds__(H_QB / (32 * NQB) * 64, (NQB == 2 ? 2 : 4)) void kn
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) cl[qb] = R::empty();
 
-    HTile<THREADS> st;
+    HTile<R, THREADS> st;
 
     if (tile0 < tile1) {
         st.load(Th, tile0, tid);
@@ -451,23 +461,24 @@ __global__ __launch_bounds__(H_QB / (32 * NQB) * 64, (NQB == 2 ? 2 : 4)) void kn
         acc A[NQB], B[NQB];
         for (int tix = 0; tix < tile1 - tile0; ++tix) {
             const int buf = tix & 1;
-            const uint4* tb = hsm + (buf * H_TT + r) * H_LDS_ROW16 + h;
-            const unsigned lb = static_cast<unsigned>(tix) * 16u;          // group ids of this tile: lb + 4*blk + g
+            const uint4* tb = hsm + (buf * H_TT + r) * R::LDS_ROW16 + h;
+            constexpr unsigned G = R::GPB;
+            const unsigned lb = static_cast<unsigned>(tix) * (4u * G);     // group ids of this tile: lb + GPB*blk + g
             // the last tile is simply staged again: past the end nothing reads the other buffer
             st.load(Th, tile0 + tix + 1 < ntiles ? tile0 + tix + 1 : tile0 + tix, tid);
             if (tix == 0) h_block<R, NQB, false>(tb, qf, A, A, 0u, par, cl);
-            else h_block<R, NQB, true>(tb, qf, A, B, lb - 4u, par, cl);                        // B = block 3 of tile-1
-            h_block<R, NQB, true>(tb + 32 * H_LDS_ROW16, qf, B, A, lb, par, cl);
-            h_block<R, NQB, true>(tb + 64 * H_LDS_ROW16, qf, A, B, lb + 4u, par, cl);
+            else h_block<R, NQB, true>(tb, qf, A, B, lb - G, par, cl);                         // B = block 3 of tile-1
+            h_block<R, NQB, true>(tb + 32 * R::LDS_ROW16, qf, B, A, lb, par, cl);
+            h_block<R, NQB, true>(tb + 64 * R::LDS_ROW16, qf, A, B, lb + G, par, cl);
             st.store(hsm, buf ^ 1, tid);
-            h_block<R, NQB, true>(tb + 96 * H_LDS_ROW16, qf, B, A, lb + 8u, par, cl);
+            h_block<R, NQB, true>(tb + 96 * R::LDS_ROW16, qf, B, A, lb + 2u * G, par, cl);
             __syncthreads();
         }
-        const unsigned lb = static_cast<unsigned>(tile1 - tile0 - 1) * 16u + 12u;
+        const unsigned lb = static_cast<unsigned>(tile1 - tile0 - 1) * (4u * R::GPB) + 3u * R::GPB;
 #pragma unroll
         for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) R::select(B[qb], par, lb + static_cast<unsigned>(g), cl[qb], g);
+            for (int g = 0; g < R::GPB; ++g) R::select(B[qb], par, lb + static_cast<unsigned>(g), cl[qb], g);
     }
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
@@ -520,7 +531,7 @@ int launch_rows288(pm_ctx* ctx, const char* name, const void* Qh, const void* Th
                    int tiles_per_split, unsigned par, void* cval, int slots, const unsigned long long* stats,
                    unsigned epoch, int mode)
 {
-    const size_t lds = sizeof(uint4) * 2 * H_TT * H_LDS_ROW16;
+    const size_t lds = sizeof(uint4) * 2 * H_TT * R::LDS_ROW16;
     static const int nqb_env = [] { const char* e = getenv("PM_KNN_F16_NQB"); return e ? atoi(e) : 0; }();
     // few tiles per workgroup: the 8-wave form covers latency better; long sweeps: the 4-wave form halves LDS reads
     const int nqb = nqb_env == 1 || nqb_env == 2 ? nqb_env : (tiles_per_split <= 8 ? 1 : 2);

@@ -16,7 +16,8 @@
 // the 4 best 4-row groups, and knn_hamming_refine re-evaluates the candidate rows with popcounts.
 // The integers are exact on both sides, so the window logic has no epsilon: a row can only be
 // missed if its sub-list overflowed, which the 4th entry reveals (then that sub-list's rows are
-// scanned).
+// scanned).  Rows padding the last 128-row tile are all-zero (dot = 0): groups that contain such a
+// row do not take part in the choice of tau, but are expanded like any other candidate.
 #include <cstdlib>
 
 #include "knn_shared.hpp"
@@ -197,34 +198,27 @@ __device__ __forceinline__ uint32_t expand_nibble(uint32_t nib)
     return 0xFFFFFFFFu ^ (ones * 0xFEu);
 }
 
-// one thread per (row, 32-byte chunk): chunks 0..7 = the 8 descriptor words, chunk 8 = seed chunk.
-// Rows >= n of the padded copy are all-zero data; a padded TRAIN row carries -128 in the seed byte,
-// every QUERY row carries 127 there: the pad rows' dot is -16256, below any real row's (>= -256).
+// one thread per (row, descriptor word): 32 bits -> 32 bytes.  Rows >= n of the padded copy are zero.
 __global__ __launch_bounds__(256) void knn_hamming_expand(const uint32_t* __restrict__ Q, int nq, int nq_pad,
                                                           const uint32_t* __restrict__ T, int nt, int nt_pad,
                                                           uint4* __restrict__ Qe, uint4* __restrict__ Te)
 {
     const int gid = blockIdx.x * 256 + threadIdx.x;
-    const int total_q = nq_pad * H_NCH;
+    const int total_q = nq_pad * I8_NCH;
     const bool is_q = gid < total_q;
     const int e = is_q ? gid : gid - total_q;
-    if (!is_q && e >= nt_pad * H_NCH) return;
-    const int row = e / H_NCH, c = e % H_NCH;
+    if (!is_q && e >= nt_pad * I8_NCH) return;
+    const int row = e / I8_NCH, c = e % I8_NCH;
     const int n = is_q ? nq : nt;
     uint4 lo = uint4{0u, 0u, 0u, 0u}, hi = uint4{0u, 0u, 0u, 0u};
-    if (c < 8) {
-        if (row < n) {
-            const uint32_t w = (is_q ? Q : T)[static_cast<size_t>(row) * 8 + c];
-            lo = uint4{expand_nibble(w & 15u), expand_nibble((w >> 4) & 15u), expand_nibble((w >> 8) & 15u),
-                       expand_nibble((w >> 12) & 15u)};
-            hi = uint4{expand_nibble((w >> 16) & 15u), expand_nibble((w >> 20) & 15u), expand_nibble((w >> 24) & 15u),
-                       expand_nibble(w >> 28)};
-        }
-    } else {
-        if (is_q) lo.x = 127u;
-        else if (row >= n) lo.x = 0x80u;
+    if (row < n) {
+        const uint32_t w = (is_q ? Q : T)[static_cast<size_t>(row) * 8 + c];
+        lo = uint4{expand_nibble(w & 15u), expand_nibble((w >> 4) & 15u), expand_nibble((w >> 8) & 15u),
+                   expand_nibble((w >> 12) & 15u)};
+        hi = uint4{expand_nibble((w >> 16) & 15u), expand_nibble((w >> 20) & 15u), expand_nibble((w >> 24) & 15u),
+                   expand_nibble(w >> 28)};
     }
-    uint4* dst = (is_q ? Qe : Te) + static_cast<size_t>(row) * H_ROW16 + 2 * c;
+    uint4* dst = (is_q ? Qe : Te) + static_cast<size_t>(row) * I8_ROW16 + 2 * c;
     dst[0] = lo;
     dst[1] = hi;
 }
@@ -260,7 +254,8 @@ __device__ __forceinline__ unsigned long long hamming_key256(const uint4 q0, con
 }
 
 // One wave per query.  cand: [nq][slots] ints, sub-list s = entries 4s..4s+3 in descending order,
-// s = split*2 + lane half; entry = (dot << shift) | gid, gid = tile_in_split*16 + block*4 + group.
+// s = split*2 + lane half; entry = (dot << shift) | gid, gid = tile_in_split*8 + block*2 + group;
+// group (block, g, half hh) = rows 32*block + 16*g + 4*hh + {0,1,2,3, 8,9,10,11} of the tile.
 constexpr int HR_MAXE = 8;          // entries per lane: slots <= 512
 __global__ __launch_bounds__(256) void knn_hamming_refine(const uint32_t* __restrict__ Q, const uint32_t* __restrict__ T,
                                                           int nq, int nt, int k, const int* __restrict__ cand,
@@ -276,21 +271,27 @@ __global__ __launch_bounds__(256) void knn_hamming_refine(const uint32_t* __rest
     const int gmask = (1 << shift) - 1;
 
     int v[HR_MAXE], dc[HR_MAXE];
+    bool whole[HR_MAXE];                                     // every row of the group is a real row
 #pragma unroll
     for (int i = 0; i < HR_MAXE; ++i) {
         const int e = lane + 64 * i;
         v[i] = e < slots ? cand[static_cast<size_t>(q) * slots + e] : I8_EMPTY;
         dc[i] = v[i] == I8_EMPTY ? 0x7FFFFFF0 : ((I8_BITS - (v[i] >> shift)) >> 1);      // coarse (= exact) distance
+        const int gid = v[i] & gmask, sub = e >> 2;
+        const int last = ((sub >> 1) * tiles_per_split + (gid >> 3)) * H_TT + 32 * ((gid >> 1) & 3) + 16 * (gid & 1) +
+                         4 * (sub & 1) + 11;
+        whole[i] = v[i] != I8_EMPTY && last < nt;
     }
-    // tau = k-th smallest entry distance (entries are distinct groups, so k distinct rows lie within tau)
+    // tau = k-th smallest distance over the entries whose rows are all real (k distinct rows lie within
+    // tau); fewer than k such entries (tiny train sets): tau = "everything"
     unsigned long long lastk = 0ull;
     int tau = 0;
     for (int c = 0; c < k; ++c) {
         unsigned long long m = ~0ull;
 #pragma unroll
         for (int i = 0; i < HR_MAXE; ++i) {
-            const unsigned long long key = (static_cast<unsigned long long>(static_cast<unsigned>(dc[i])) << 32) |
-                                           static_cast<unsigned>(lane + 64 * i);
+            const unsigned dt = whole[i] ? static_cast<unsigned>(dc[i]) : 0x7FFFFFF0u;
+            const unsigned long long key = (static_cast<unsigned long long>(dt) << 32) | static_cast<unsigned>(lane + 64 * i);
             if ((c == 0 || key > lastk) && key < m) m = key;
         }
         m = wave_min_u64(m);
@@ -307,7 +308,8 @@ __global__ __launch_bounds__(256) void knn_hamming_refine(const uint32_t* __rest
         const unsigned long long full = __ballot(within && (lane & 3) == 3);
         const bool my_full = (full >> (lane | 3)) & 1ull;
         const unsigned long long cm = __ballot(within && !my_full);
-        if (within && !my_full) clist[wave][total + __popcll(cm & ((1ull << lane) - 1ull))] = (v[i] & gmask) | (((lane + 64 * i) >> 2) << 16);
+        if (within && !my_full)
+            clist[wave][total + __popcll(cm & ((1ull << lane) - 1ull))] = (v[i] & gmask) | (((lane + 64 * i) >> 2) << 16);
         total += __popcll(cm);
         unsigned long long f = full;
         while (f) {                                          // rare
@@ -322,14 +324,15 @@ __global__ __launch_bounds__(256) void knn_hamming_refine(const uint32_t* __rest
             }
         }
     }
-    // candidate groups: 4 rows each, one row per lane, 16 groups per round
-    for (int base = 0; base < 4 * total; base += 64) {
+    // candidate groups: 8 rows each, one row per lane, 8 groups per round
+    for (int base = 0; base < 8 * total; base += 64) {
         const int t = base + lane;
-        if (t < 4 * total) {
-            const int ent = clist[wave][t >> 2];
+        if (t < 8 * total) {
+            const int ent = clist[wave][t >> 3];
             const int gid = ent & 0xFFFF, sub = ent >> 16, split = sub >> 1, hh = sub & 1;
-            const int tile = gid >> 4, rem = gid & 15;
-            const int row = (split * tiles_per_split + tile) * H_TT + 32 * (rem >> 2) + 8 * (rem & 3) + 4 * hh + (t & 3);
+            const int s8 = t & 7;
+            const int row = (split * tiles_per_split + (gid >> 3)) * H_TT + 32 * ((gid >> 1) & 3) + 16 * (gid & 1) + 4 * hh +
+                            8 * (s8 >> 2) + (s8 & 3);
             if (row < nt) best.insert(hamming_key256(q0, q1, T, row));
         }
     }
@@ -361,10 +364,10 @@ int run_mfma(pm_ctx* ctx, const uint32_t* dq, int nq, const uint32_t* dt, int nt
     splits = (ntiles + tiles_per_split - 1) / tiles_per_split;
     const int slots = splits * 2 * KNN_C;
     constexpr int shift = I8_SHIFT;
-    if (tiles_per_split * (H_TT / 8) > (1 << shift)) return PM_OK;      // > 64k groups per lane stream: VALU route
+    if (tiles_per_split * (H_TT / 16) > (1 << shift)) return PM_OK;     // > 64k groups per lane stream: VALU route
 
     const size_t cb = sizeof(int) * static_cast<size_t>(nq) * slots;
-    const size_t qe = sizeof(uint4) * static_cast<size_t>(nq_pad) * H_ROW16, te = sizeof(uint4) * static_cast<size_t>(nt_pad) * H_ROW16;
+    const size_t qe = sizeof(uint4) * static_cast<size_t>(nq_pad) * I8_ROW16, te = sizeof(uint4) * static_cast<size_t>(nt_pad) * I8_ROW16;
     const size_t need = pm::align_up(cb, 256) + pm::align_up(qe, 256) + pm::align_up(te, 256) + 1024;
     int rc = pm::arena_reserve(ctx, need);
     if (rc != PM_OK) return rc;
@@ -375,7 +378,7 @@ int run_mfma(pm_ctx* ctx, const uint32_t* dq, int nq, const uint32_t* dt, int nt
     PM_REQUIRE(cval && Qe && Te, PM_E_NOMEM, "scratch arena too small");
     {
         pm::ScopedKernelTime t(ctx, "knn_hamming_expand");
-        const int total = (nq_pad + nt_pad) * H_NCH;
+        const int total = (nq_pad + nt_pad) * I8_NCH;
         hipLaunchKernelGGL(knn_hamming_expand, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, dq, nq, nq_pad, dt, nt,
                            nt_pad, Qe, Te);
         PM_HIP_CHECK(hipGetLastError());

@@ -30,10 +30,15 @@ constexpr float H_MAXABS = 361.f;       // 128 * 361^2 < 2^24
 constexpr int H_ROW16 = H_ROW / 8;      // 16-byte units per global row (18)
 constexpr int H_LDS_ROW16 = H_LDS_ROW / 8;   // 16-byte units per LDS row (19)
 
-// i8 route (256-bit binary descriptors expanded to +-1 bytes; same 288-byte row geometry: 8 data
-// chunks of 32 bytes + one seed chunk whose first byte is 127 for queries and -128 for pad rows)
+// i8 route (256-bit binary descriptors expanded to +-1 bytes): 256-byte rows = 8 chunks of 32 bytes,
+// no seed chunk (rows padding the last tile are all-zero: dot = 0, the refinement knows them by
+// their index); row groups of 8 rows
 constexpr int I8_BITS = 256;
-constexpr int I8_SHIFT = 16;             // candidate = (dot << 16) | group id; |dot| <= 16512 fits
+constexpr int I8_NCH = 8;
+constexpr int I8_ROW16 = 16;
+constexpr int I8_LDS_ROW16 = 17;        // 272-byte LDS rows: 16 rows of a lane group hit 16 different slots
+constexpr int I8_GROUP_ROWS = 8;
+constexpr int I8_SHIFT = 16;             // candidate = (dot << 16) | group id, |dot| <= 256
 constexpr int I8_EMPTY = static_cast<int>(0x80000000u);   // an unfilled list entry
 
 // Enqueue the f32-MFMA coarse pass (dim % 4 == 0, dim <= 128).  only_if_ineligible != 0: the
