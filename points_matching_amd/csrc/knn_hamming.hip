@@ -223,15 +223,7 @@ __global__ __launch_bounds__(256) void knn_hamming_expand(const uint32_t* __rest
     dst[1] = hi;
 }
 
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
-{
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        const unsigned long long w = __shfl_xor(v, o, 64);
-        v = w < v ? w : v;
-    }
-    return v;
-}
+using pm::wave_min_u64;
 
 struct Best2 {
     unsigned long long a, b;       // a <= b

@@ -86,22 +86,8 @@ __device__ __forceinline__ float l2sqr_canonical(const float* __restrict__ a,
     return d;
 }
 
-__device__ __forceinline__ float wave_min_f32(float v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-
-__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        uint64_t w = __shfl_xor(v, o, 64);
-        v = w < v ? w : v;
-    }
-    return v;
-}
+using pm::wave_min_f32;
+using pm::wave_min_u64;
 
 // ---------------------------------------------------------------------------------------------
 // prep: squared norms of the query rows and the train rows in ONE launch (64 rows per block, 16

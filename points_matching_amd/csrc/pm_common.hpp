@@ -91,4 +91,51 @@ struct ScopedKernelTime {
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+#if defined(__HIPCC__)
+// Wave-wide reductions on the DPP path (all 64 lanes must be active): four v_min/v_max with a
+// row_ror operand reduce each row of 16 lanes, four v_readlane + scalar ops combine the rows; the
+// result is wave-uniform.  A __shfl_xor butterfly costs six ds_bpermute round trips (two each for
+// 64-bit values) — several hundred cycles per reduction in the one-wave-per-query refinements.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v)
+{
+    return static_cast<unsigned>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+    v = min(v, dpp_u32<0x121>(v));      // row_ror:1
+    v = min(v, dpp_u32<0x122>(v));      // row_ror:2
+    v = min(v, dpp_u32<0x124>(v));      // row_ror:4
+    v = min(v, dpp_u32<0x128>(v));      // row_ror:8
+    const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return min(min(a, b), min(c, d));
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) { return ~wave_min_u32(~v); }
+// lexicographic (high word, low word): exact 64-bit minimum in two 32-bit reductions
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+{
+    const unsigned hi = static_cast<unsigned>(v >> 32), lo = static_cast<unsigned>(v);
+    const unsigned mh = wave_min_u32(hi);
+    const unsigned ml = wave_min_u32(hi == mh ? lo : 0xFFFFFFFFu);
+    return (static_cast<unsigned long long>(mh) << 32) | ml;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) { return ~wave_min_u64(~v); }
+// float minimum with fminf semantics on non-NaN data (the callers' values are finite)
+__device__ __forceinline__ float wave_min_f32(float v)
+{
+#define PM_DPP_F(ctrl) __uint_as_float(dpp_u32<ctrl>(__float_as_uint(v)))
+    v = fminf(v, PM_DPP_F(0x121));
+    v = fminf(v, PM_DPP_F(0x122));
+    v = fminf(v, PM_DPP_F(0x124));
+    v = fminf(v, PM_DPP_F(0x128));
+#undef PM_DPP_F
+    const float a = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 0));
+    const float b = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 16));
+    const float c = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 32));
+    const float d = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 48));
+    return fminf(fminf(a, b), fminf(c, d));
+}
+#endif
+
 }  // namespace pm
