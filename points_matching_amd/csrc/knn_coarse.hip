@@ -426,6 +426,11 @@ __global__ __launch_bounds__(H_QB / (32 * NQB) * 64, (NQB == 2 ? 2 : 4)) void kn
     const int r = lane & 31, h = lane >> 5;
     const int qbase = blockIdx.x * H_QB + wave * 32 * NQB;
 
+    // both global streams are requested before anything waits: the first train tile, then the query fragments
+    HTile<R, THREADS> st;
+    const int ntiles = (nt + H_TT - 1) / H_TT;
+    const int tile0 = blockIdx.y * tiles_per_split;
+    st.load(Th, tile0 < ntiles ? tile0 : ntiles - 1, tid);      // unconditional (clamped): nt >= 1
     frag qf[NQB][R::NCH];
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb)
@@ -444,18 +449,13 @@ __global__ __launch_bounds__(H_QB / (32 * NQB) * 64, (NQB == 2 ? 2 : 4)) void kn
             qf[qb][c] = __builtin_bit_cast(frag, t);
         }
 
-    const int ntiles = (nt + H_TT - 1) / H_TT;
-    const int tile0 = blockIdx.y * tiles_per_split;
     int tile1 = tile0 + tiles_per_split;
     if (tile1 > ntiles) tile1 = ntiles;
     list cl[NQB];
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) cl[qb] = R::empty();
 
-    HTile<R, THREADS> st;
-
     if (tile0 < tile1) {
-        st.load(Th, tile0, tid);
         st.store(hsm, 0, tid);
         __syncthreads();
         acc A[NQB], B[NQB];

@@ -761,8 +761,6 @@ extern "C" int pm_bf_knn_l2_f32_dev(pm_ctx* ctx, const float* dq, int nq, const 
                "scratch arena too small");
     g32.cand = cval32;
     g16.cand = cval16;
-    ctx->dbg_ptr = want16 ? cval16 : cval32;
-    ctx->dbg_bytes = want16 ? c16 : c32;
 
     unsigned long long* stats = ctx->knn_stats;          // persistent, epoch-tagged: never cleared
     if (++ctx->knn_epoch == 0u) {              // 2^32 calls: restart the epoch tags

@@ -239,15 +239,6 @@ int pm_ctx_knn_stats(pm_ctx* ctx, int* rescans, int* nonfinite)
     return PM_OK;
 }
 
-// undocumented debugging aid (not in pm.h): copies the matcher's last coarse candidate buffer
-int pm_debug_copy(pm_ctx* ctx, void* dst, size_t bytes)
-{
-    PM_REQUIRE(ctx && dst && ctx->dbg_ptr, PM_E_INVALID, "nothing to copy");
-    PM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    PM_HIP_CHECK(hipMemcpy(dst, ctx->dbg_ptr, bytes < ctx->dbg_bytes ? bytes : ctx->dbg_bytes, hipMemcpyDeviceToHost));
-    return static_cast<int>(ctx->dbg_bytes);
-}
-
 // ---- strong-match filters (slot of main.cpp:49-69) -----------------------------------------
 
 int pm_filter_midpoint(const pm_match* m, int n, double* min_out, double* max_out,

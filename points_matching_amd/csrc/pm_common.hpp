@@ -68,9 +68,6 @@ struct pm_ctx {
     // stable compaction: epoch-tagged per-block survivor counts
     unsigned* fg_counts = nullptr;
     unsigned fg_epoch = 0;
-    // debugging aid: last candidate buffer of the matcher (device pointer inside the arena)
-    const void* dbg_ptr = nullptr;
-    size_t dbg_bytes = 0;
 };
 
 namespace pm {
