@@ -159,6 +159,9 @@ def main():
     ap.add_argument("--exercise-exchange", action="store_true",
                     help="debugging: run the N>1 code path (all-gather, concat, key all-reduce, model from key) "
                          "even with one rank")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="debugging: gloo lets a multi-rank run share ONE GPU (with --single-device); the driver uses nccl")
+    ap.add_argument("--single-device", action="store_true", help="debugging: every rank uses cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
@@ -179,13 +182,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     multi = world > 1 or args.exercise_exchange
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        if world > 1:
+        if args.backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        elif world > 1:
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
