@@ -226,6 +226,23 @@ int pm_lmeds_fundamental_dev(pm_ctx* ctx, const float* d_xy1, const float* d_xy2
                              const pm_lmeds_params* p, double* d_F, uint8_t* d_mask,
                              int32_t* d_n_inliers, int64_t* d_best_model, double* d_median);
 int pm_lmeds_default_iters(double confidence, double outlier_ratio);
+/* The adaptive-iteration RANSAC variant of the same family (OpenCV 2.4 CV_FM_RANSAC [recalled];
+ * docs/SPEC.md S16): 7-point models, a correspondence is an inlier when its symmetric-epipolar
+ * residual is <= thresh_px^2; hypotheses are visited in id order, a model with more inliers than
+ * any before becomes the best and shrinks the iteration budget to
+ * log(1 - confidence) / log(1 - (inliers/n)^7) (never above max_iters; OpenCV's defaults: 2000, 0.99,
+ * 3 px).  The result equals OpenCV's sequential loop on these models; the device solves and counts
+ * ahead in batches.  *iters_run = hypotheses visited. */
+typedef struct pm_adaptive_params {
+    int64_t  max_iters;
+    double   confidence;
+    float    thresh_px;
+    int32_t  reserved;
+    uint64_t seed;
+} pm_adaptive_params;
+int pm_ransac7_adaptive(pm_ctx* ctx, const float* xy1, const float* xy2, int n,
+                        const pm_adaptive_params* p, double F[9], uint8_t* mask, int* n_inliers,
+                        int64_t* best_model, int* iters_run);
 
 /* ---- batch of independent image pairs (BASELINE config C5) ----------------------------------
  * One pass of main.cpp:46 -> :49-69 (ratio form) -> :89-91 -> :95-98 per pair, streamed: the batch

@@ -746,6 +746,64 @@ int pmo_lmeds_fundamental(const float* xy1, const float* xy2, int n, const pmo_l
     return 0;
 }
 
+/* SPEC S16 — OpenCV 2.4's adaptive-iteration RANSAC over 7-point models (CV_FM_RANSAC)
+ * [structure recalled: CvModelEstimator2::runRANSAC + cvRANSACUpdateNumIters]. */
+typedef struct pmo_adaptive_params { int64_t max_iters; double confidence; float thresh_px; int32_t pad; uint64_t seed; } pmo_adaptive_params;
+
+int pmo_ransac_update_num_iters(double p, double ep, int model_points, int max_iters)
+{
+    p = p > 0.0 ? p : 0.0; p = p < 1.0 ? p : 1.0;
+    ep = ep > 0.0 ? ep : 0.0; ep = ep < 1.0 ? ep : 1.0;
+    double num = 1.0 - p > DBL_MIN ? 1.0 - p : DBL_MIN;
+    double denom = 1.0 - pow(1.0 - ep, (double)model_points);
+    if (denom < DBL_MIN) return 0;
+    num = log(num);
+    denom = log(denom);
+    return (denom >= 0.0 || -num >= (double)max_iters * (-denom)) ? max_iters : (int)lround(num / denom);
+}
+
+int pmo_ransac7_adaptive(const float* xy1, const float* xy2, int n, const pmo_adaptive_params* p, double F[9],
+                         uint8_t* mask, int* n_inliers, int64_t* best_model, int* iters_run)
+{
+    if (F) for (int i = 0; i < 9; ++i) F[i] = 0.0;
+    if (mask) memset(mask, 0, (size_t)(n > 0 ? n : 0));
+    if (n_inliers) *n_inliers = 0;
+    if (best_model) *best_model = -1;
+    if (iters_run) *iters_run = 0;
+    if (n < 8) return -2;
+    if (p->max_iters < 1 || p->max_iters > (1 << 20)) return -1;
+    const double thr = (double)p->thresh_px * (double)p->thresh_px;
+    int niters = (int)p->max_iters, best = 6, h = 0;
+    int64_t best_id = -1;
+    double bestF[9] = {0};
+    for (; h < niters; ++h) {
+        double Fm[27]; int valid[3];
+        if (!pmo_hyp_models7(xy1, xy2, n, p->seed, (uint64_t)h, Fm, valid)) continue;
+        for (int r = 0; r < 3; ++r) {
+            if (!valid[r]) continue;
+            int c = 0;
+            for (int i = 0; i < n; ++i)
+                c += (double)lmeds_err(Fm + 9 * r, xy1[2 * i], xy1[2 * i + 1], xy2[2 * i], xy2[2 * i + 1]) <= thr;
+            if (c > best) {
+                best = c; best_id = 3 * (int64_t)h + r; memcpy(bestF, Fm + 9 * r, sizeof bestF);
+                niters = pmo_ransac_update_num_iters(p->confidence, (double)(n - c) / (double)n, 7, niters);
+            }
+        }
+    }
+    if (iters_run) *iters_run = h;
+    if (best_id < 0) return -3;
+    int cnt = 0;
+    for (int i = 0; i < n; ++i) {
+        int in = (double)lmeds_err(bestF, xy1[2 * i], xy1[2 * i + 1], xy2[2 * i], xy2[2 * i + 1]) <= thr;
+        if (mask) mask[i] = (uint8_t)in;
+        cnt += in;
+    }
+    if (F) memcpy(F, bestF, sizeof bestF);
+    if (n_inliers) *n_inliers = cnt;
+    if (best_model) *best_model = best_id;
+    return 0;
+}
+
 /* main.cpp:103-123 — residual report.  transposed != 0 is the reference literally:
  * temp1 = [x1 y1 1] (1x3, main.cpp:110-112), temp2 = [x2 y2 1]^T (main.cpp:113-115),
  * result = temp1 * F * temp2 (main.cpp:117), sum += abs(result) (main.cpp:120). */

@@ -190,6 +190,25 @@ def lmeds_fundamental(xy1, xy2, iters, seed, hyp_begin=0, nthreads=1):
     return rc, F.reshape(3, 3), mask[:n], ninl.value, best.value, med.value
 
 
+class AdaptiveParams(C.Structure):
+    _fields_ = [("max_iters", C.c_int64), ("confidence", C.c_double), ("thresh_px", C.c_float), ("pad", C.c_int32),
+                ("seed", C.c_uint64)]
+
+
+def ransac7_adaptive(xy1, xy2, max_iters, confidence, thresh_px, seed):
+    """SPEC S16.  Returns (status, F(3x3), mask, n_inliers, best_model, iters_run)."""
+    xy1 = np.ascontiguousarray(xy1, np.float32)
+    xy2 = np.ascontiguousarray(xy2, np.float32)
+    n = xy1.shape[0]
+    prm = AdaptiveParams(max_iters, confidence, thresh_px, 0, seed)
+    F = np.zeros(9, np.float64)
+    mask = np.zeros(max(n, 1), np.uint8)
+    ninl, best, it = C.c_int(), C.c_int64(), C.c_int()
+    rc = lib().pmo_ransac7_adaptive(_p(xy1), _p(xy2), n, C.byref(prm), _p(F), _p(mask), C.byref(ninl), C.byref(best),
+                                    C.byref(it))
+    return rc, F.reshape(3, 3), mask[:n], ninl.value, best.value, it.value
+
+
 def sample7(seed, h, n):
     idx = np.zeros(7, np.int32)
     lib().pmo_sample7(C.c_uint64(seed), C.c_uint64(h), n, _p(idx))

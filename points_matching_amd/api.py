@@ -36,7 +36,7 @@ EXPORTS = [
     "pm_ransac_fundamental", "pm_ransac_score_dev", "pm_ransac_score_devn", "pm_ransac_model_from_hyp",
     "pm_ransac_model_from_key_dev", "pm_ransac_run_dev",
     "pm_batch_create", "pm_batch_destroy", "pm_batch_run", "pm_host_register", "pm_host_unregister",
-    "pm_lmeds_fundamental", "pm_lmeds_fundamental_dev", "pm_lmeds_default_iters",
+    "pm_lmeds_fundamental", "pm_lmeds_fundamental_dev", "pm_lmeds_default_iters", "pm_ransac7_adaptive",
     "pm_epipolar_residuals", "pm_f_scale_f33", "pm_epilines", "pm_epiline_endpoints",
 ]
 
@@ -329,6 +329,28 @@ class Context:
 
 class LmedsParams(C.Structure):
     _fields_ = [("hyp_begin", C.c_int64), ("hyp_end", C.c_int64), ("seed", C.c_uint64)]
+
+
+class AdaptiveParams(C.Structure):
+    _fields_ = [("max_iters", C.c_int64), ("confidence", C.c_double), ("thresh_px", C.c_float), ("reserved", C.c_int32),
+                ("seed", C.c_uint64)]
+
+
+def ransac7_adaptive(ctx, xy1, xy2, max_iters, confidence, thresh_px, seed):
+    """Adaptive-iteration RANSAC over 7-point models (SPEC S16).
+    Returns (status, F(3x3), mask, n_inliers, best_model, iters_run)."""
+    xy1 = np.ascontiguousarray(xy1, np.float32).reshape(-1, 2)
+    xy2 = np.ascontiguousarray(xy2, np.float32).reshape(-1, 2)
+    n = xy1.shape[0]
+    prm = AdaptiveParams(max_iters, confidence, thresh_px, 0, seed)
+    F = np.zeros(9, np.float64)
+    mask = np.zeros(max(n, 1), np.uint8)
+    ninl, best, it = C.c_int(), C.c_int64(), C.c_int()
+    rc = lib().pm_ransac7_adaptive(ctx._h, _p(xy1), _p(xy2), n, C.byref(prm), _p(F), _p(mask), C.byref(ninl),
+                                   C.byref(best), C.byref(it))
+    if rc not in (PM_OK, PM_E_NO_MODEL, PM_E_TOO_FEW):
+        _check(rc)
+    return rc, F.reshape(3, 3), mask[:n], ninl.value, best.value, it.value
 
 
 def lmeds_default_iters(confidence=0.99, outlier_ratio=0.45):

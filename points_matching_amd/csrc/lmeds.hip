@@ -13,6 +13,9 @@
 //   lmeds_median   one workgroup per model: fp64 symmetric-epipolar residuals of all n
 //                  correspondences (as float keys in LDS), exact median by 4-pass radix select
 //   lmeds_final    one workgroup: smallest (median, model id), robust sigma, inlier mask (S15)
+#include <cfloat>
+#include <cmath>
+
 #include "pm_common.hpp"
 
 namespace {
@@ -442,6 +445,78 @@ __global__ __launch_bounds__(256) void lmeds_final(const float* __restrict__ xy1
     }
 }
 
+// ---- adaptive-iteration RANSAC over the same 7-point models (SPEC S16) --------------------------
+// one workgroup per model: number of correspondences with residual <= thr (fp64 compare of the
+// float residual, as OpenCV's findInliers)
+__global__ __launch_bounds__(256) void fm_count(const float* __restrict__ xy1, const float* __restrict__ xy2, int n,
+                                                const double* __restrict__ models, const int* __restrict__ mvalid,
+                                                double thr, int* __restrict__ counts)
+{
+    __shared__ int wcnt[4];
+    const int model = blockIdx.x;
+    if (!mvalid[model]) {                              // uniform
+        if (threadIdx.x == 0) counts[model] = -1;
+        return;
+    }
+    double F[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) F[i] = models[static_cast<size_t>(model) * 9 + i];
+    int mine = 0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float2 p = *reinterpret_cast<const float2*>(xy1 + 2 * static_cast<size_t>(i));
+        const float2 pp = *reinterpret_cast<const float2*>(xy2 + 2 * static_cast<size_t>(i));
+        mine += static_cast<double>(lmeds_err(F, p, pp)) <= thr ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[model] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+}
+
+// F and mask of one given model (slot `win` of the current batch), one workgroup
+__global__ __launch_bounds__(256) void fm_mask(const float* __restrict__ xy1, const float* __restrict__ xy2, int n,
+                                               const double* __restrict__ models, int win, double thr,
+                                               LmedsOut* __restrict__ out, uint8_t* __restrict__ mask)
+{
+    __shared__ int wcnt[4];
+    double F[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) F[i] = models[static_cast<size_t>(win) * 9 + i];
+    int mine = 0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float2 p = *reinterpret_cast<const float2*>(xy1 + 2 * static_cast<size_t>(i));
+        const float2 pp = *reinterpret_cast<const float2*>(xy2 + 2 * static_cast<size_t>(i));
+        const bool in = static_cast<double>(lmeds_err(F, p, pp)) <= thr;
+        mask[i] = in ? 1 : 0;
+        mine += in ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) out->F[i] = F[i];
+        out->n_inliers = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        out->found = 1;
+    }
+}
+
+// OpenCV cvRANSACUpdateNumIters [recalled]; host libm, as in the oracle
+int update_num_iters(double p, double ep, int model_points, int max_iters)
+{
+    p = p > 0.0 ? p : 0.0; p = p < 1.0 ? p : 1.0;
+    ep = ep > 0.0 ? ep : 0.0; ep = ep < 1.0 ? ep : 1.0;
+    double num = 1.0 - p > DBL_MIN ? 1.0 - p : DBL_MIN;
+    double denom = 1.0 - pow(1.0 - ep, static_cast<double>(model_points));
+    if (denom < DBL_MIN) return 0;
+    num = log(num);
+    denom = log(denom);
+    return (denom >= 0.0 || -num >= static_cast<double>(max_iters) * (-denom)) ? max_iters
+                                                                               : static_cast<int>(lround(num / denom));
+}
+
 int check_lmeds(const pm_lmeds_params* p, int n)
 {
     PM_REQUIRE(p != nullptr, PM_E_INVALID, "params is null");
@@ -557,5 +632,98 @@ extern "C" int pm_lmeds_fundamental(pm_ctx* ctx, const float* xy1, const float* 
     if (n_inliers) *n_inliers = h->n_inliers;
     if (best_model) *best_model = h->best_model;
     if (median) *median = h->median;
+    return PM_OK;
+}
+
+// SPEC S16.  The hypotheses are solved and counted on the device in batches of ADAPT_BATCH ids; the
+// host replays OpenCV's sequential loop over the counts (best model so far, shrinking iteration
+// budget) and stops requesting batches once the budget is reached.
+extern "C" int pm_ransac7_adaptive(pm_ctx* ctx, const float* xy1, const float* xy2, int n, const pm_adaptive_params* p,
+                                   double F[9], uint8_t* mask, int* n_inliers, int64_t* best_model, int* iters_run)
+{
+    constexpr int ADAPT_BATCH = 512;
+    if (F) for (int i = 0; i < 9; ++i) F[i] = 0.0;
+    if (mask && n > 0) memset(mask, 0, static_cast<size_t>(n));
+    if (n_inliers) *n_inliers = 0;
+    if (best_model) *best_model = -1;
+    if (iters_run) *iters_run = 0;
+    PM_REQUIRE(ctx != nullptr && p != nullptr, PM_E_INVALID, "null ctx / params");
+    PM_REQUIRE(n >= 0 && (n == 0 || (xy1 && xy2)), PM_E_INVALID, "bad point arrays");
+    PM_REQUIRE(p->max_iters >= 1 && p->max_iters <= (1 << 20) && p->thresh_px > 0.f, PM_E_INVALID,
+               "need 1 <= max_iters <= 2^20 and thresh_px > 0");
+    if (n < 8) { pm::set_error("need at least 8 correspondences, got %d", n); return PM_E_TOO_FEW; }
+    PM_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t xyb = sizeof(float) * 2 * static_cast<size_t>(n);
+    const int nm = 3 * ADAPT_BATCH;
+    const size_t need = 2 * pm::align_up(xyb, 256) + pm::align_up(static_cast<size_t>(n), 256) +
+                        3 * pm::align_up(sizeof(double) * 9 * nm, 256) + 2 * pm::align_up(sizeof(int) * nm, 256) + 4096;
+    int rc = pm::arena_reserve(ctx, need);
+    if (rc != PM_OK) return rc;
+    rc = pm::pinned_reserve(ctx, sizeof(LmedsOut) + sizeof(int) * nm);
+    if (rc != PM_OK) return rc;
+    pm::arena_reset(ctx);
+    float* dxy1 = static_cast<float*>(pm::arena_take(ctx, xyb));
+    float* dxy2 = static_cast<float*>(pm::arena_take(ctx, xyb));
+    uint8_t* dmask = static_cast<uint8_t*>(pm::arena_take(ctx, static_cast<size_t>(n)));
+    double* models = static_cast<double*>(pm::arena_take(ctx, sizeof(double) * 9 * nm));
+    double* best_models = static_cast<double*>(pm::arena_take(ctx, sizeof(double) * 9));
+    int* mvalid = static_cast<int*>(pm::arena_take(ctx, sizeof(int) * nm));
+    int* counts = static_cast<int*>(pm::arena_take(ctx, sizeof(int) * nm));
+    LmedsOut* d_out = static_cast<LmedsOut*>(pm::arena_take(ctx, sizeof(LmedsOut)));
+    PM_REQUIRE(dxy1 && dxy2 && dmask && models && best_models && mvalid && counts && d_out, PM_E_NOMEM,
+               "scratch arena too small");
+    LmedsOut* h_out = static_cast<LmedsOut*>(ctx->pinned);
+    int* h_counts = reinterpret_cast<int*>(h_out + 1);
+    PM_HIP_CHECK(hipMemcpyAsync(dxy1, xy1, xyb, hipMemcpyHostToDevice, ctx->stream));
+    PM_HIP_CHECK(hipMemcpyAsync(dxy2, xy2, xyb, hipMemcpyHostToDevice, ctx->stream));
+    const double thr = static_cast<double>(p->thresh_px) * static_cast<double>(p->thresh_px);
+    int niters = static_cast<int>(p->max_iters), best = 6, h = 0;
+    long long best_id = -1;
+    while (h < niters) {
+        const int h0 = h;
+        int nb = niters - h0;
+        if (nb > ADAPT_BATCH) nb = ADAPT_BATCH;
+        {
+            pm::ScopedKernelTime t(ctx, "lmeds_solve");
+            hipLaunchKernelGGL(lmeds_solve, dim3((nb + 63) / 64), dim3(64), 0, ctx->stream, dxy1, dxy2, n, p->seed,
+                               static_cast<int64_t>(h0), nb, models, mvalid);
+            PM_HIP_CHECK(hipGetLastError());
+        }
+        {
+            pm::ScopedKernelTime t(ctx, "fm_count");
+            hipLaunchKernelGGL(fm_count, dim3(3 * nb), dim3(256), 0, ctx->stream, dxy1, dxy2, n, models, mvalid, thr, counts);
+            PM_HIP_CHECK(hipGetLastError());
+        }
+        PM_HIP_CHECK(hipMemcpyAsync(h_counts, counts, sizeof(int) * 3 * nb, hipMemcpyDeviceToHost, ctx->stream));
+        PM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        int batch_best = -1;
+        for (; h < niters && h < h0 + nb; ++h)
+            for (int r = 0; r < 3; ++r) {
+                const int c = h_counts[3 * (h - h0) + r];
+                if (c > best) {
+                    best = c;
+                    best_id = 3ll * h + r;
+                    batch_best = 3 * (h - h0) + r;
+                    niters = update_num_iters(p->confidence, static_cast<double>(n - c) / static_cast<double>(n), 7, niters);
+                }
+            }
+        if (batch_best >= 0)      // keep the running winner's model: the batch buffer is overwritten by the next batch
+            PM_HIP_CHECK(hipMemcpyAsync(best_models, models + static_cast<size_t>(batch_best) * 9, sizeof(double) * 9,
+                                        hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (iters_run) *iters_run = h;
+    if (best_id < 0) {
+        (void)hipStreamSynchronize(ctx->stream);
+        pm::set_error("no 7-point model with more than 6 inliers");
+        return PM_E_NO_MODEL;
+    }
+    hipLaunchKernelGGL(fm_mask, dim3(1), dim3(256), 0, ctx->stream, dxy1, dxy2, n, best_models, 0, thr, d_out, dmask);
+    PM_HIP_CHECK(hipGetLastError());
+    PM_HIP_CHECK(hipMemcpyAsync(h_out, d_out, sizeof(LmedsOut), hipMemcpyDeviceToHost, ctx->stream));
+    if (mask) PM_HIP_CHECK(hipMemcpyAsync(mask, dmask, static_cast<size_t>(n), hipMemcpyDeviceToHost, ctx->stream));
+    PM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (F) memcpy(F, h_out->F, sizeof(h_out->F));
+    if (n_inliers) *n_inliers = h_out->n_inliers;
+    if (best_model) *best_model = best_id;
     return PM_OK;
 }
