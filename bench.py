@@ -391,8 +391,8 @@ def main():
                            "traffic": pmc_traffic("c4:knn_hamming_mfma_i8", nq, nt),
                            "algorithmic_bytes": (nq + nt) * dim + nq * K * 16,
                            "dtype": "i8 (+-1 expanded bits) x i8 -> i32 MFMA; exact",
-                           "note": "VALU-issue bound next to the matrix pipe: grouped (8-row) top-4 selection, 1.1 VALU ops "
-                                   "per pair; every issued MFMA is algorithmic work (no seed chunk)"}
+                           "note": "ablation (DESIGN.md 2.1): MFMA skeleton 76% of the kernel, staging 12%, grouped (8-row) "
+                                   "selection 3%; every issued MFMA is algorithmic work (no seed chunk)"}
     elif hamming and "knn_hamming" in kern:
         # 16 integer VALU ops per pair (8 x v_xor_b32 + 8 x v_bcnt_u32_b32 at 32 B); one wave64 VALU
         # instruction occupies its SIMD 4 cycles: 1024 SIMDs * 64 lanes * 2.4 GHz / 4 = 3.93e13 lane-ops/s
@@ -409,8 +409,8 @@ def main():
                            "traffic": pmc_traffic("c3:knn_l2_mfma_f16", nq, nt),
                            "algorithmic_bytes": (nq + nt) * dim * 4 + nq * K * 16,
                            "dtype": "f16-input MFMA, f32 accumulate (v_mfma_f32_32x32x16_f16), exact for u8-valued data",
-                           "note": "VALU-issue bound: the grouped top-4 selection costs 1.75 VALU ops per pair next to "
-                                   "9 MFMAs per 1024 pairs; see DESIGN.md"}
+                           "note": "launch/prologue-sized at C3: 19.4 us remain with selection, staging, barrier and LDS reads "
+                                   "all removed (ablation, DESIGN.md 2.1); 8.8 us of pure matrix-pipe time"}
     elif "knn_l2_mfma" in kern:
         ach = flops / (kern["knn_l2_mfma"] * 1e-6) / 1e12
         out["roofline"] = {"kernel": "knn_l2_mfma", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
@@ -442,18 +442,31 @@ def main():
         knn_cpu = O.bf_knn_hamming if hamming else O.bf_knn_l2
         m = knn_cpu(w["q"][:sample_q], w["t"], K, nthreads=1)
         t_knn = time.perf_counter() - t0
-        good = O.filter_ratio(knn_cpu(w["q"], w["t"], K, nthreads=os.cpu_count() or 1), ratio)
+        nth = max(1, min(os.cpu_count() or 1, 16))      # the GPU box gives a 1-GPU job a 16-core share
+        t0 = time.perf_counter()
+        good = O.filter_ratio(knn_cpu(w["q"], w["t"], K, nthreads=nth), ratio)
+        t_knn_all = time.perf_counter() - t0
         xs1 = O.gather_points(w["kp1"], good["queryIdx"])
         xs2 = O.gather_points(w["kp2"], good["trainIdx"])
         t0 = time.perf_counter()
         O.ransac_fundamental(xs1, xs2, H, thresh, seed, nthreads=1)
         t_r = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        O.ransac_fundamental(xs1, xs2, H, thresh, seed, nthreads=nth)
+        t_r_all = time.perf_counter() - t0
+        try:
+            cpu_model = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
+        except (OSError, IndexError):
+            cpu_model = "unknown"
         out["cpu_baseline"] = {
             "value": sample_q * nt / t_knn, "unit": "pairs/s", "cores": 1, "kind": "port",
             "sample": "oracle (CPU restatement, AVX2-vectorised by gcc, 1 thread): matcher on the first %d of %d "
                       "query rows x %d train rows; RANSAC-F on the full %d hypotheses x %d matches"
                       % (sample_q, nq, nt, H, good.size),
-            "ransac_hyp_per_s": H / t_r, "host_cpus": os.cpu_count(),
+            "ransac_hyp_per_s": H / t_r, "host_cpus": os.cpu_count(), "cpu_model": cpu_model,
+            "threads_%d" % nth: {"value": float(nq) * nt / t_knn_all, "ransac_hyp_per_s": H / t_r_all, "cores": nth,
+                                 "sample": "full %d x %d matcher and the full RANSAC run, OpenMP over query rows / "
+                                           "hypothesis ids" % (nq, nt)},
         }
     print(json.dumps(out))
     if multi:

@@ -386,10 +386,20 @@ __device__ __forceinline__ void h_block(const uint4* __restrict__ tb, const type
 #pragma unroll
     for (int c = 0; c < R::NCH; ++c) {
         const frag x = ring[c % 3];
+#ifndef PM_ABL_NOLDSREAD
         if (c + 3 < R::NCH) ring[c % 3] = *reinterpret_cast<const frag*>(tb + 2 * (c + 3));
+#endif
 #pragma unroll
         for (int qb = 0; qb < NQB; ++qb) a[qb] = R::mfma(x, qf[qb][c], c == 0 ? R::zero() : a[qb]);
+#ifdef PM_ABL_NOEPI
+        if (EPI && c == 1) {                      // timing-only build: the accumulators stay live, nothing is selected
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb) asm volatile("" ::"v"(p[qb]));
+        }
+        if (false) {
+#else
         if (EPI && c >= 1) {                      // GPB*NQB row groups spread over chunks 1..NCH-1
+#endif
             constexpr int NGB = R::GPB * NQB;
 #pragma unroll
             for (int e = (c - 1) * NGB / (R::NCH - 1); e < c * NGB / (R::NCH - 1); ++e)   // query column e % NQB, group e / NQB
@@ -465,14 +475,20 @@ __global__ __launch_bounds__(H_QB / (32 * NQB) * 64, (NQB == 2 ? 2 : 4)) void kn
             constexpr unsigned G = R::GPB;
             const unsigned lb = static_cast<unsigned>(tix) * (4u * G);     // group ids of this tile: lb + GPB*blk + g
             // the last tile is simply staged again: past the end nothing reads the other buffer
+#ifndef PM_ABL_NOSTAGE
             st.load(Th, tile0 + tix + 1 < ntiles ? tile0 + tix + 1 : tile0 + tix, tid);
+#endif
             if (tix == 0) h_block<R, NQB, false>(tb, qf, A, A, 0u, par, cl);
             else h_block<R, NQB, true>(tb, qf, A, B, lb - G, par, cl);                         // B = block 3 of tile-1
             h_block<R, NQB, true>(tb + 32 * R::LDS_ROW16, qf, B, A, lb, par, cl);
             h_block<R, NQB, true>(tb + 64 * R::LDS_ROW16, qf, A, B, lb + G, par, cl);
+#ifndef PM_ABL_NOSTAGE
             st.store(hsm, buf ^ 1, tid);
+#endif
             h_block<R, NQB, true>(tb + 96 * R::LDS_ROW16, qf, B, A, lb + 2u * G, par, cl);
+#ifndef PM_ABL_NOBARRIER
             __syncthreads();
+#endif
         }
         const unsigned lb = static_cast<unsigned>(tile1 - tile0 - 1) * (4u * R::GPB) + 3u * R::GPB;
 #pragma unroll

@@ -736,9 +736,8 @@ int score_shard(pm_ctx* ctx, const float* dxy1, const float* dxy2, int n, const 
     // workgroup columns over the correspondences: about 16 workgroups per CU in total, never more
     // columns than minimum-size chunks of the largest possible count
     const int hb = (nh + 255) / 256;
-    static const int wgs_per_cu = [] { const char* e = getenv("PM_SCORE_WGS_PER_CU"); return e ? atoi(e) : 16; }();
-    int chunks = (wgs_per_cu * ctx->n_cu + hb - 1) / hb;
-    static const int min_chunk = [] { const char* e = getenv("PM_SCORE_MIN_CHUNK"); return e ? atoi(e) : SCORE_MIN_CHUNK; }();
+    int chunks = (16 * ctx->n_cu + hb - 1) / hb;
+    constexpr int min_chunk = SCORE_MIN_CHUNK;
     const int max_chunks = (n + min_chunk - 1) / min_chunk;
     if (chunks > max_chunks) chunks = max_chunks;
     if (chunks < 1) chunks = 1;
