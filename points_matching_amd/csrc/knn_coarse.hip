@@ -510,7 +510,8 @@ int launch_mfma(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt, i
 {
     constexpr int LDT = NCH * 8 + 4;
     const size_t lds = 2 * TT * LDT * sizeof(float);
-    static bool attr_done = false;
+    static bool attr_done_dev[PM_MAX_DEVICES] = {};          // the attribute is per device (and per template instance)
+    bool& attr_done = attr_done_dev[ctx->device];
     if (!attr_done) {
         PM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_l2_mfma<NCH, FULL, TT>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
@@ -551,7 +552,8 @@ int launch_rows288(pm_ctx* ctx, const char* name, const void* Qh, const void* Th
     static const int nqb_env = [] { const char* e = getenv("PM_KNN_F16_NQB"); return e ? atoi(e) : 0; }();
     // few tiles per workgroup: the 8-wave form covers latency better; long sweeps: the 4-wave form halves LDS reads
     const int nqb = nqb_env == 1 || nqb_env == 2 ? nqb_env : (tiles_per_split <= 8 ? 1 : 2);
-    static bool attr_done = false;
+    static bool attr_done_dev[PM_MAX_DEVICES] = {};          // the attribute is per device (and per template instance)
+    bool& attr_done = attr_done_dev[ctx->device];
     if (!attr_done) {
         PM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_mfma_rows288<R, 1>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));

@@ -224,37 +224,61 @@ __global__ __launch_bounds__(256) void knn_hamming_expand(const uint32_t* __rest
 }
 
 using pm::wave_min_u64;
+using pm::wave_min_u32;
 
+// (distance, row) keys: 32-bit (distance << 23 | row) while the train set has fewer than 2^23 rows
+// (distance <= 256), 64-bit otherwise.  Half the VALU work of the one-wave-per-query refinement is
+// key handling, so the narrow form matters.
+struct Key32 {
+    typedef uint32_t type;
+    static constexpr type NONE = 0xFFFFFFFFu;
+    static __device__ __forceinline__ type make(int d, int row) { return (static_cast<uint32_t>(d) << 23) | static_cast<uint32_t>(row); }
+    static __device__ __forceinline__ int dist(type k) { return static_cast<int>(k >> 23); }
+    static __device__ __forceinline__ int row(type k) { return static_cast<int>(k & 0x7FFFFFu); }
+    static __device__ __forceinline__ type wave_min(type k) { return wave_min_u32(k); }
+};
+struct Key64 {
+    typedef unsigned long long type;
+    static constexpr type NONE = ~0ull;
+    static __device__ __forceinline__ type make(int d, int row) { return (static_cast<type>(d) << 32) | static_cast<unsigned>(row); }
+    static __device__ __forceinline__ int dist(type k) { return static_cast<int>(k >> 32); }
+    static __device__ __forceinline__ int row(type k) { return static_cast<int>(k & 0xFFFFFFFFull); }
+    static __device__ __forceinline__ type wave_min(type k) { return wave_min_u64(k); }
+};
+
+template <typename KT>
 struct Best2 {
-    unsigned long long a, b;       // a <= b
-    __device__ __forceinline__ void insert(unsigned long long key)
+    KT a, b;       // a <= b
+    __device__ __forceinline__ void insert(KT key)
     {
         if (key < a) { b = a; a = key; }
         else if (key < b) b = key;
     }
 };
 
-__device__ __forceinline__ unsigned long long hamming_key256(const uint4 q0, const uint4 q1,
-                                                             const uint32_t* __restrict__ T, int row)
+__device__ __forceinline__ int hamming256(const uint4 q0, const uint4 q1, const uint32_t* __restrict__ T, int row)
 {
     const uint4* tr = reinterpret_cast<const uint4*>(T + static_cast<size_t>(row) * 8);
     const uint4 t0 = tr[0], t1 = tr[1];
     const int d = __builtin_popcount(q0.x ^ t0.x) + __builtin_popcount(q0.y ^ t0.y) + __builtin_popcount(q0.z ^ t0.z) +
                   __builtin_popcount(q0.w ^ t0.w) + __builtin_popcount(q1.x ^ t1.x) + __builtin_popcount(q1.y ^ t1.y) +
                   __builtin_popcount(q1.z ^ t1.z) + __builtin_popcount(q1.w ^ t1.w);
-    return (static_cast<unsigned long long>(d) << 32) | static_cast<unsigned>(row);
+    return d;
 }
 
 // One wave per query.  cand: [nq][slots] ints, sub-list s = entries 4s..4s+3 in descending order,
 // s = split*2 + lane half; entry = (dot << shift) | gid, gid = tile_in_split*8 + block*2 + group;
 // group (block, g, half hh) = rows 32*block + 16*g + 4*hh + {0,1,2,3, 8,9,10,11} of the tile.
 constexpr int HR_MAXE = 8;          // entries per lane: slots <= 512
+// NE = entries per lane actually needed (ceil(slots / 64) rounded up to 1, 2, 4 or 8): the per-entry
+// work below is unrolled NE times, and with few splits (C4: 32 slots) NE = 1 instead of 8
+template <int NE, typename K>
 __global__ __launch_bounds__(256) void knn_hamming_refine(const uint32_t* __restrict__ Q, const uint32_t* __restrict__ T,
                                                           int nq, int nt, int k, const int* __restrict__ cand,
                                                           int slots, int tiles_per_split, int shift,
                                                           pm_match* __restrict__ out)
 {
-    __shared__ int clist[4][64 * HR_MAXE];
+    __shared__ int clist[4][64 * NE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + wave;
     if (q >= nq) return;                                     // wave-uniform; no block barriers below
@@ -262,10 +286,10 @@ __global__ __launch_bounds__(256) void knn_hamming_refine(const uint32_t* __rest
     const uint4 q0 = qr[0], q1 = qr[1];
     const int gmask = (1 << shift) - 1;
 
-    int v[HR_MAXE], dc[HR_MAXE];
-    bool whole[HR_MAXE];                                     // every row of the group is a real row
+    int v[NE], dc[NE];
+    bool whole[NE];                                     // every row of the group is a real row
 #pragma unroll
-    for (int i = 0; i < HR_MAXE; ++i) {
+    for (int i = 0; i < NE; ++i) {
         const int e = lane + 64 * i;
         v[i] = e < slots ? cand[static_cast<size_t>(q) * slots + e] : I8_EMPTY;
         dc[i] = v[i] == I8_EMPTY ? 0x7FFFFFF0 : ((I8_BITS - (v[i] >> shift)) >> 1);      // coarse (= exact) distance
@@ -276,25 +300,27 @@ __global__ __launch_bounds__(256) void knn_hamming_refine(const uint32_t* __rest
     }
     // tau = k-th smallest distance over the entries whose rows are all real (k distinct rows lie within
     // tau); fewer than k such entries (tiny train sets): tau = "everything"
-    unsigned long long lastk = 0ull;
+    // (keys: distance << 16 | entry index, distances <= 256 or the 0x7FFF sentinel, entries < 512)
+    unsigned lastk = 0u;
     int tau = 0;
     for (int c = 0; c < k; ++c) {
-        unsigned long long m = ~0ull;
+        unsigned m = 0xFFFFFFFFu;
 #pragma unroll
-        for (int i = 0; i < HR_MAXE; ++i) {
-            const unsigned dt = whole[i] ? static_cast<unsigned>(dc[i]) : 0x7FFFFFF0u;
-            const unsigned long long key = (static_cast<unsigned long long>(dt) << 32) | static_cast<unsigned>(lane + 64 * i);
+        for (int i = 0; i < NE; ++i) {
+            const unsigned dt = whole[i] ? static_cast<unsigned>(dc[i]) : 0x7FFFu;
+            const unsigned key = (dt << 16) | static_cast<unsigned>(lane + 64 * i);
             if ((c == 0 || key > lastk) && key < m) m = key;
         }
-        m = wave_min_u64(m);
+        m = wave_min_u32(m);
         lastk = m;
-        tau = static_cast<int>(m >> 32);
+        tau = static_cast<int>(m >> 16);
     }
+    if (tau == 0x7FFF) tau = 0x7FFFFFFF;                     // fewer than k whole groups: everything is a candidate
     // sub-lists whose 4th entry is within tau may have dropped a row within tau: scan them whole
-    Best2 best{~0ull, ~0ull};
+    Best2<typename K::type> best{K::NONE, K::NONE};
     int total = 0;
 #pragma unroll
-    for (int i = 0; i < HR_MAXE; ++i) {
+    for (int i = 0; i < NE; ++i) {
         if (64 * i >= slots) break;                          // wave-uniform
         const bool within = v[i] != I8_EMPTY && dc[i] <= tau;
         const unsigned long long full = __ballot(within && (lane & 3) == 3);
@@ -312,7 +338,7 @@ __global__ __launch_bounds__(256) void knn_hamming_refine(const uint32_t* __rest
                 const int tile = idx >> 6, rem = idx & 63;
                 const int row = (split * tiles_per_split + tile) * H_TT + 32 * (rem >> 4) + 8 * ((rem >> 2) & 3) + 4 * hh +
                                 (rem & 3);
-                if (row < nt) best.insert(hamming_key256(q0, q1, T, row));
+                if (row < nt) best.insert(K::make(hamming256(q0, q1, T, row), row));
             }
         }
     }
@@ -325,25 +351,26 @@ __global__ __launch_bounds__(256) void knn_hamming_refine(const uint32_t* __rest
             const int s8 = t & 7;
             const int row = (split * tiles_per_split + (gid >> 3)) * H_TT + 32 * ((gid >> 1) & 3) + 16 * (gid & 1) + 4 * hh +
                             8 * (s8 >> 2) + (s8 & 3);
-            if (row < nt) best.insert(hamming_key256(q0, q1, T, row));
+            if (row < nt) best.insert(K::make(hamming256(q0, q1, T, row), row));
         }
     }
     for (int c = 0; c < k; ++c) {
-        const unsigned long long m = wave_min_u64(best.a);
-        if (best.a == m && m != ~0ull) { best.a = best.b; best.b = ~0ull; }      // keys are unique rows
+        const typename K::type m = K::wave_min(best.a);
+        if (best.a == m && m != K::NONE) { best.a = best.b; best.b = K::NONE; }      // keys are unique rows
         if (lane == 0) {
             pm_match mm;
             mm.queryIdx = q;
             mm.imgIdx = 0;
-            if (m == ~0ull) { mm.trainIdx = -1; mm.distance = HM_INF; }
-            else { mm.trainIdx = static_cast<int>(m & 0xFFFFFFFFull); mm.distance = static_cast<float>(static_cast<int>(m >> 32)); }
+            if (m == K::NONE) { mm.trainIdx = -1; mm.distance = HM_INF; }
+            else { mm.trainIdx = K::row(m); mm.distance = static_cast<float>(K::dist(m)); }
             out[static_cast<size_t>(q) * k + c] = mm;
         }
     }
 }
 
 // 256-bit descriptors, k <= 2
-int run_mfma(pm_ctx* ctx, const uint32_t* dq, int nq, const uint32_t* dt, int nt, int k, pm_match* dout, bool* done)
+int run_mfma(pm_ctx* ctx, const uint32_t* dq, int nq, const uint32_t* dt, int nt, int k, pm_match* dout, bool wide_keys,
+             bool* done)
 {
     *done = false;
     const int nq_pad = (nq + H_QB - 1) / H_QB * H_QB, nt_pad = (nt + H_TT - 1) / H_TT * H_TT;
@@ -379,8 +406,20 @@ int run_mfma(pm_ctx* ctx, const uint32_t* dq, int nq, const uint32_t* dt, int nt
     if (rc != PM_OK) return rc;
     {
         pm::ScopedKernelTime t(ctx, "knn_hamming_refine");
-        hipLaunchKernelGGL(knn_hamming_refine, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, dq, dt, nq, nt, k, cval, slots,
-                           tiles_per_split, shift, dout);
+#define PM_HREFINE(NE_, K_)                                                                                      \
+    hipLaunchKernelGGL((knn_hamming_refine<NE_, K_>), dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, dq, dt, nq, nt, k, \
+                       cval, slots, tiles_per_split, shift, dout)
+#define PM_HREFINE_K(K_)                    \
+    do {                                    \
+        if (slots <= 64) PM_HREFINE(1, K_); \
+        else if (slots <= 128) PM_HREFINE(2, K_); \
+        else if (slots <= 256) PM_HREFINE(4, K_); \
+        else PM_HREFINE(HR_MAXE, K_);       \
+    } while (0)
+        if (nt < (1 << 23) && !wide_keys) PM_HREFINE_K(Key32);
+        else PM_HREFINE_K(Key64);
+#undef PM_HREFINE_K
+#undef PM_HREFINE
         PM_HIP_CHECK(hipGetLastError());
     }
     *done = true;
@@ -404,12 +443,14 @@ extern "C" int pm_bf_knn_hamming_u8_dev(pm_ctx* ctx, const uint8_t* dq, int nq, 
     const uint32_t* q32 = reinterpret_cast<const uint32_t*>(dq);
     const uint32_t* t32 = reinterpret_cast<const uint32_t*>(dt);
     const int nw = bytes / 4;
-    const char* route_env = getenv("PM_HAMMING_ROUTE");          // "valu" pins the VALU scan (tests, A/B timing)
+    // tests / A-B timing: "valu" pins the VALU scan, "wide" the 64-bit-key refinement of the matrix-core route
+    const char* route_env = getenv("PM_HAMMING_ROUTE");
     const bool force_valu = route_env && route_env[0] == 'v';
+    const bool wide_keys = route_env && route_env[0] == 'w';
     if (bytes * 8 == I8_BITS && k <= 2 && nt >= 1 && !force_valu &&
         (reinterpret_cast<uintptr_t>(dq) & 15) == 0 && (reinterpret_cast<uintptr_t>(dt) & 15) == 0) {
         bool done = false;
-        const int rc = run_mfma(ctx, q32, nq, t32, nt, k, dout, &done);
+        const int rc = run_mfma(ctx, q32, nq, t32, nt, k, dout, wide_keys, &done);
         if (rc != PM_OK || done) return rc;
     }
     if (k == 1) return run_passes<1>(ctx, q32, nq, t32, nt, nw, k, dout);

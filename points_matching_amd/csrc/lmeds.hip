@@ -552,7 +552,8 @@ int run_lmeds(pm_ctx* ctx, const float* dxy1, const float* dxy2, int n, const pm
             PM_HIP_CHECK(hipGetLastError());
         }
         const size_t lds = sizeof(uint32_t) * (static_cast<size_t>(n) + 256 + 4 + 2);
-        static size_t lds_set = 0;
+        static size_t lds_set_dev[PM_MAX_DEVICES] = {};        // per device: largest size granted so far
+        size_t& lds_set = lds_set_dev[ctx->device];
         if (lds > lds_set) {
             PM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lmeds_median),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));

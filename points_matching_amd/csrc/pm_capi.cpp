@@ -130,7 +130,7 @@ int pm_ctx_create(int device, pm_ctx** out)
     *out = nullptr;
     int n = 0;
     PM_HIP_CHECK(hipGetDeviceCount(&n));
-    PM_REQUIRE(device >= 0 && device < n, PM_E_INVALID, "no such HIP device");
+    PM_REQUIRE(device >= 0 && device < n && device < PM_MAX_DEVICES, PM_E_INVALID, "no such HIP device");
     PM_HIP_CHECK(hipSetDevice(device));
     pm_ctx* c = new (std::nothrow) pm_ctx();
     PM_REQUIRE(c != nullptr, PM_E_NOMEM, "host allocation failed");

@@ -43,6 +43,8 @@ struct KernelTimer {
 
 }  // namespace pm
 
+constexpr int PM_MAX_DEVICES = 64;      // per-device one-time state (kernel attributes) is kept in arrays of this size
+
 struct pm_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;

@@ -69,8 +69,11 @@ def test_hamming_i8_route_matches_valu_route_and_oracle(ctx, oracle, nq, nt, k, 
     got = ctx.bf_knn_hamming(q, t, k)
     monkeypatch.setenv("PM_HAMMING_ROUTE", "valu")
     valu = ctx.bf_knn_hamming(q, t, k)
+    monkeypatch.setenv("PM_HAMMING_ROUTE", "wide")          # 64-bit keys (what >= 2^23 train rows would take)
+    wide = ctx.bf_knn_hamming(q, t, k)
     monkeypatch.delenv("PM_HAMMING_ROUTE")
     assert_matches_equal(got, valu, "i8 vs valu")
+    assert_matches_equal(got, wide, "32-bit vs 64-bit keys")
     assert_matches_equal(got, oracle.bf_knn_hamming(q, t, k), "i8 vs oracle")
 
 
