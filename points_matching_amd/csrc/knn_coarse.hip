@@ -283,8 +283,8 @@ __global__ __launch_bounds__(256, (TT == 64 ? 2 : 1)) void knn_l2_mfma(
 // MFMAs), walks the 128-row tile one 32-row block at a time and selects block b-1 between the
 // MFMAs of block b, with two alternating accumulator sets.
 // ---------------------------------------------------------------------------------------------
-// The kernel is shared by two routes with the same byte geometry (288-B rows = 9 k-chunks of 32 B,
-// 16 B per lane and MFMA):
+// The kernel is shared by two routes with the same structure (rows of NCH k-chunks of 32 B, 16 B per
+// lane and MFMA; 288-byte rows with a seed chunk for f16, 256-byte rows for i8):
 //   RouteF16  v_mfma_f32_32x32x16_f16, values float, group id in the low mantissa bits;
 //   RouteI8   v_mfma_i32_32x32x32_i8 on +-1 bytes (binary descriptors: dot = bits - 2*hamming),
 //             values int, candidate = (dot << I8_SHIFT) | group id.

@@ -12,8 +12,8 @@
 // 256-bit descriptors with k <= 2 (ORB + ratio test: config C4) take the matrix-core route
 // instead: the bits are expanded to +-1 bytes, so that v_mfma_i32_32x32x32_i8 yields
 // dot = 256 - 2*hamming for 32x32 pairs per instruction (16x the VALU rate); the coarse kernel is
-// knn_coarse.hip's 288-byte-row kernel (shared with the f16 L2 route) keeping, per lane stream,
-// the 4 best 4-row groups, and knn_hamming_refine re-evaluates the candidate rows with popcounts.
+// knn_coarse.hip's row-streaming kernel (shared with the f16 L2 route) keeping, per lane stream,
+// the 4 best 8-row groups, and knn_hamming_refine re-evaluates the candidate rows with popcounts.
 // The integers are exact on both sides, so the window logic has no epsilon: a row can only be
 // missed if its sub-list overflowed, which the 4th entry reveals (then that sub-list's rows are
 // scanned).  Rows padding the last 128-row tile are all-zero (dot = 0): groups that contain such a
