@@ -340,15 +340,20 @@ __device__ __forceinline__ float l2sqr_canonical_coop8(const float* __restrict__
     return d;
 }
 
-template <bool VEC4>
+// NS = candidate-list entries a lane holds (ceil(slots / 64) rounded up to 1, 2, 4 or 8): the slot
+// values are read ONCE into registers, the candidates of all lists are compacted into one per-wave
+// LDS list and evaluated together (8 rows per round), so neither the number of lists nor the way the
+// candidates spread over them adds rounds.  (This kernel is VALU-issue bound: one wave per query.)
+template <bool VEC4, int NS>
 __global__ __launch_bounds__(256) void knn_l2_refine(
     const float* __restrict__ Q, const float* __restrict__ T, const float* __restrict__ qnorm,
     const unsigned long long* __restrict__ stats, unsigned epoch, unsigned* __restrict__ diag, int nq, int nt,
     int dim, int k, KnnGeom g16, KnnGeom g32, int route, pm_match* __restrict__ out)
 {
-    const int lane = threadIdx.x & 63;
-    const int q = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (q >= nq) return;
+    __shared__ int clist[4][64 * NS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    if (q >= nq) return;                                     // wave-uniform; no block barriers below
     const float* qp = Q + static_cast<size_t>(q) * dim;
     const float na = qnorm[q];
     const unsigned long long s0 = stats[0], s1 = stats[1];
@@ -361,31 +366,30 @@ __global__ __launch_bounds__(256) void knn_l2_refine(
     const KnnGeom g = use16 ? g16 : g32;
     const int slots = g.slots, tiles_per_split = g.tiles_per_split, rows_per_tile = g.rows_per_tile;
     const unsigned lid_mask = g.lid_mask;
-    const float eps_coef = g.eps_coef, embed_coef = g.embed_coef;
-    const float* __restrict__ cand_val = g.cand;
     // window half-width: fp error of the coarse value + truncation by the embedded row id
-    const float eps = eps_coef * (na + tmax) + embed_coef * (na + 2.f * tmax);
-    const float* cv = cand_val + static_cast<size_t>(q) * slots;
-    // slot value w = q.t - ||t||^2/2 (+id bits)  ->  coarse squared distance d2a = ||q||^2 - 2w
-    auto coarse = [&](int s) -> float {
-        const float w = cv[s];
-        return w > -1.0e38f ? fmaf(-2.f, w, na) : KNN_INF;
-    };
-    // first of the 4 consecutive rows of the group a slot names (group id in the low mantissa bits)
-    auto row_of = [&](int s) -> int {
-        const unsigned gid = __float_as_uint(cv[s]) & lid_mask;
-        const int split = s / (2 * KNN_C), hh = (s / KNN_C) & 1;
-        const int gshift = 31 - __clz(rows_per_tile >> 3);                      // groups per tile = rows/8 = 2^shift
-        const int tile = static_cast<int>(gid >> gshift), rem = static_cast<int>(gid & ((1u << gshift) - 1u));
-        return (split * tiles_per_split + tile) * rows_per_tile + 32 * (rem >> 2) + 8 * (rem & 3) + 4 * hh;
-    };
+    const float eps = g.eps_coef * (na + tmax) + g.embed_coef * (na + 2.f * tmax);
+    const float* cv = g.cand + static_cast<size_t>(q) * slots;
+    const int gshift = 31 - __clz(rows_per_tile >> 3);       // groups per tile = rows/8 = 2^gshift
 
-    // k-th smallest coarse value over all slots (k <= 2)
+    // slot s = lane + 64*i: value w = q.t - ||t||^2/2 (+id bits) -> coarse squared distance
+    // d2a = ||q||^2 - 2w; first of the 4 consecutive rows of the group the slot names
+    float val[NS];
+    int row0[NS];
     float m0 = KNN_INF, m1 = KNN_INF;
-    for (int s = lane; s < slots; s += 64) {
-        const float v = coarse(s);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int s = lane + 64 * i;
+        const float w = s < slots ? cv[s] : -KNN_INF;
+        const float v = w > -1.0e38f ? fmaf(-2.f, w, na) : KNN_INF;
+        const unsigned gid = __float_as_uint(w) & lid_mask;
+        const int split = s >> 3, hh = (s >> 2) & 1;          // s / (2*KNN_C), (s / KNN_C) & 1
+        const int tile = static_cast<int>(gid >> gshift), rem = static_cast<int>(gid & ((1u << gshift) - 1u));
+        val[i] = v;
+        row0[i] = (split * tiles_per_split + tile) * rows_per_tile + 32 * (rem >> 2) + 8 * (rem & 3) + 4 * hh;
         if (v < m1) { if (v < m0) { m1 = m0; m0 = v; } else { m1 = v; } }
     }
+    static_assert(KNN_C == 4, "slot decoding assumes 4 entries per list");
+    // k-th smallest coarse value over all slots (k <= 2)
     float tau = KNN_INF;
     for (int round = 0; round < k; ++round) {
         tau = wave_min_f32(m0);
@@ -405,33 +409,25 @@ __global__ __launch_bounds__(256) void knn_l2_refine(
         const int grp = lane >> 3, l = lane & 7;
         const int ids = rows_per_tile >> 1;                 // rows a lane sees per tile (a power of two)
         const int ids_shift2 = 31 - __clz(ids);
-        for (int base = 0; base < slots; base += 64) {
-            const int s = base + lane;
+        int total = 0;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            if (64 * i >= slots) break;                     // wave-uniform
+            const int s = lane + 64 * i;
             const bool in = s < slots;
-            const float v = in ? coarse(s) : KNN_INF;
-            const int j = in ? row_of(s) : 0;
+            const float v = val[i];
+            const int j = row0[i];
             // a sub-list (4 consecutive slots) whose 4th entry is inside the window may have
             // dropped candidates: its rows are scanned below instead of trusting its slots
             unsigned long long spilled = __ballot(in && (s & (KNN_C - 1)) == KNN_C - 1 && v <= thr);
             const bool mine_spilled = (spilled >> (lane | (KNN_C - 1))) & 1ull;
-            const unsigned long long cand = __ballot(in && v <= thr && j < nt && !mine_spilled);
-            const int nc = 4 * __popcll(cand);             // every candidate group is 4 consecutive rows
-            for (int r0 = 0; r0 < nc; r0 += 8) {           // 8 rows per round, 8 lanes each
-                const int rank = r0 + grp;
-                const bool live0 = rank < nc;
-                const int src = nth_set_bit(cand, live0 ? rank >> 2 : 0);
-                int jj = __shfl(j, src, 64) + (rank & 3);
-                const bool live = live0 && jj < nt;
-                jj = jj < nt ? jj : nt - 1;
-                const float d2 = l2sqr_canonical_coop8(qp, T + static_cast<size_t>(jj) * dim, dim, l);
-                if (live && l == 0) {
-                    const float d = __builtin_sqrtf(d2);
-                    best2_insert(b, knn_key(d, jj), d);
-                }
-            }
+            const bool is_cand = in && v <= thr && j < nt && !mine_spilled;
+            const unsigned long long cand = __ballot(is_cand);
+            if (is_cand) clist[wave][total + __popcll(cand & ((1ull << lane) - 1ull))] = j;
+            total += __popcll(cand);
             if (diag && lane == 0 && spilled) atomicAdd(&diag[0], static_cast<unsigned>(__popcll(spilled)));
-            while (spilled) {                               // wave-uniform
-                const int sub = (base + __ffsll(static_cast<long long>(spilled)) - 1) / KNN_C;
+            while (spilled) {                               // wave-uniform, rare
+                const int sub = (64 * i + __ffsll(static_cast<long long>(spilled)) - 1) / KNN_C;
                 spilled &= spilled - 1ull;
                 const int split = sub >> 1, hh = sub & 1;
                 for (int lid = lane; lid < tiles_per_split * ids; lid += 64) {
@@ -444,6 +440,19 @@ __global__ __launch_bounds__(256) void knn_l2_refine(
                         best2_insert(b, knn_key(d, row), d);
                     }
                 }
+            }
+        }
+        const int nc = 4 * total;                           // every candidate group is 4 consecutive rows
+        for (int r0 = 0; r0 < nc; r0 += 8) {                // 8 rows per round, 8 lanes each
+            const int rank = r0 + grp;
+            const bool live0 = rank < nc;
+            int jj = clist[wave][live0 ? rank >> 2 : 0] + (rank & 3);
+            const bool live = live0 && jj < nt;
+            jj = jj < nt ? jj : nt - 1;
+            const float d2 = l2sqr_canonical_coop8(qp, T + static_cast<size_t>(jj) * dim, dim, l);
+            if (live && l == 0) {
+                const float d = __builtin_sqrtf(d2);
+                best2_insert(b, knn_key(d, jj), d);
             }
         }
     } else {
@@ -798,8 +807,15 @@ extern "C" int pm_bf_knn_l2_f32_dev(pm_ctx* ctx, const float* dq, int nq, const 
     }
     {
         pm::ScopedKernelTime t(ctx, "knn_l2_refine");
-        hipLaunchKernelGGL(knn_l2_refine<true>, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, dq, dt, qnorm, stats,
-                           epoch, diag, nq, nt, dim, k, g16, g32, route, dout);
+        const int max_slots = (want16 ? g16.slots : 0) > (want32 ? g32.slots : 0) ? g16.slots : g32.slots;
+#define PM_REFINE(NS_)                                                                                             \
+    hipLaunchKernelGGL((knn_l2_refine<true, NS_>), dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, dq, dt, qnorm, stats, \
+                       epoch, diag, nq, nt, dim, k, g16, g32, route, dout)
+        if (max_slots <= 64) PM_REFINE(1);
+        else if (max_slots <= 128) PM_REFINE(2);
+        else if (max_slots <= 256) PM_REFINE(4);
+        else PM_REFINE(8);
+#undef PM_REFINE
         PM_HIP_CHECK(hipGetLastError());
     }
     return PM_OK;
