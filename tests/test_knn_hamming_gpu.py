@@ -116,3 +116,26 @@ def test_hamming_i8_cluster_in_one_group_stream(ctx, oracle):
         t[r, 31] ^= np.uint8(1 << (i % 8))          # distance 1 each
     t[1000] = q[0]
     assert_matches_equal(ctx.bf_knn_hamming(q, t, 2), oracle.bf_knn_hamming(q, t, 2), "cluster")
+
+
+def test_hamming_randomised_shapes(ctx, oracle):
+    """Seeded sweep over shapes, descriptor sizes and k: both routes must give the oracle's answer."""
+    rng = np.random.default_rng(0xBEEF)
+    for case in range(30):
+        nq = int(rng.integers(1, 900))
+        nt = int(rng.integers(1, 1500))
+        nbytes = int(rng.choice([4, 16, 32, 32, 32, 64]))
+        k = int(rng.choice([1, 2, 2, 3, 5]))
+        if case % 3 == 0:                              # few distinct values: ties everywhere
+            base = rng.integers(0, 256, (4, nbytes), dtype=np.uint8)
+            q = base[rng.integers(0, 4, nq)].copy()
+            t = base[rng.integers(0, 4, nt)].copy()
+            t[::5, 0] ^= 1
+        else:
+            q = rng.integers(0, 256, (nq, nbytes), dtype=np.uint8)
+            t = rng.integers(0, 256, (nt, nbytes), dtype=np.uint8)
+            sel = rng.integers(0, nt, max(1, nq // 2))
+            q[:sel.size] = t[sel]
+            q[:sel.size, rng.integers(0, nbytes)] ^= np.uint8(rng.integers(0, 256))
+        assert_matches_equal(ctx.bf_knn_hamming(q, t, k), oracle.bf_knn_hamming(q, t, k),
+                             "case %d: nq=%d nt=%d bytes=%d k=%d" % (case, nq, nt, nbytes, k))

@@ -162,3 +162,37 @@ def test_knn_integer_eligibility_edge(ctx, oracle):
     want = oracle.bf_knn_l2(q, t, 2)
     for flags in (0, PM_KNN_HINT_INTEGER, PM_KNN_FORCE_F32):
         assert_matches_equal(ctx.bf_knn_l2(q, t, 2, flags), want, "beyond flags=%d" % flags)
+
+
+def test_knn_randomised_shapes_values_and_routes(ctx, oracle):
+    """Seeded sweep over shapes, dims, k, value families and coarse routes: every combination must
+    give the oracle's bits (indices and distance patterns)."""
+    rng = np.random.default_rng(0xC0FFEE)
+    flags_all = [0, pm.api.PM_KNN_FORCE_F32, pm.api.PM_KNN_HINT_INTEGER, pm.api.PM_KNN_FORCE_EXACT]
+    for case in range(40):
+        nq = int(rng.integers(1, 700))
+        nt = int(rng.integers(1, 900))
+        dim = int(rng.choice([4, 8, 12, 20, 32, 36, 64, 100, 128]))
+        k = int(rng.choice([1, 2, 2, 3]))
+        fam = case % 4
+        if fam == 0:                                   # integer-valued (SIFT-like), some exceeding the f16 bound
+            q = rng.integers(0, 256, (nq, dim)).astype(np.float32)
+            t = rng.integers(0, 256, (nt, dim)).astype(np.float32)
+            if case % 8 == 4:
+                t[rng.integers(0, nt), rng.integers(0, dim)] = 1000.0
+        elif fam == 1:                                 # general floats of mixed scale
+            q = (rng.standard_normal((nq, dim)) * 10.0 ** rng.integers(-3, 4)).astype(np.float32)
+            t = (rng.standard_normal((nt, dim)) * 10.0 ** rng.integers(-3, 4)).astype(np.float32)
+        elif fam == 2:                                 # many exact duplicates and near ties
+            base = rng.integers(0, 4, (5, dim)).astype(np.float32)
+            q = base[rng.integers(0, 5, nq)]
+            t = base[rng.integers(0, 5, nt)]
+            t[::3] += np.float32(2.0 ** -20)
+        else:                                          # unit-norm (SURF-like) with planted neighbours
+            t = rng.standard_normal((nt, dim)).astype(np.float32)
+            t /= np.linalg.norm(t, axis=1, keepdims=True) + 1e-12
+            q = t[rng.integers(0, nt, nq)] + (rng.standard_normal((nq, dim)) * 0.01).astype(np.float32)
+        flags = flags_all[int(rng.integers(0, 4))]
+        got = ctx.bf_knn_l2(q, t, k, flags)
+        want = oracle.bf_knn_l2(q, t, k, nthreads=4)
+        assert_matches_equal(got, want, "case %d: nq=%d nt=%d dim=%d k=%d fam=%d flags=%d" % (case, nq, nt, dim, k, fam, flags))

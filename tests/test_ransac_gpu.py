@@ -112,3 +112,19 @@ def test_ransac_c3_full(ctx, oracle):
     r, mean_abs = pm.api.epipolar_residuals(x1[mask], x2[mask], pm.api.f_scale_f33(got[1]), transposed=0)
     r_o, mean_o = oracle.epipolar_residuals(x1[mask], x2[mask], oracle.f_scale_f33(want[1]), 0)
     assert (r == r_o).all() and mean_abs == mean_o
+
+
+def test_ransac_randomised(ctx, oracle):
+    """Seeded sweep over match counts, hypothesis ranges, thresholds and error kinds."""
+    rng = np.random.default_rng(0xFACE)
+    for case in range(16):
+        n = int(rng.integers(8, 3000))
+        iters = int(rng.integers(1, 1500))
+        hb = int(rng.integers(0, 2 ** 20))
+        thr = float(rng.choice([0.5, 1.0, 3.0]))
+        kind = int(rng.choice([PM_ERR_SAMPSON, PM_ERR_SYM_EPIPOLAR]))
+        x1, x2, _, _ = synth.two_view(n, seed=1000 + case, outlier_frac=float(rng.uniform(0, 0.6)),
+                                      noise_px=float(rng.uniform(0, 1.5)))
+        got = ctx.ransac_fundamental(x1, x2, hb + iters, thr, 77 + case, kind, hyp_begin=hb)
+        want = oracle.ransac_fundamental(x1, x2, hb + iters, thr, 77 + case, kind, hyp_begin=hb, nthreads=4)
+        _same(got, want, "case %d: n=%d iters=%d hb=%d thr=%g kind=%d" % (case, n, iters, hb, thr, kind))
