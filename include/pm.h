@@ -130,6 +130,12 @@ int pm_filter_ratio(const pm_match* knn, int nq, int k, float ratio, pm_match* o
 int pm_filter_ratio_gather_dev(pm_ctx* ctx, const pm_match* d_knn, int nq, int k, float ratio,
                                const float* d_kp1_xy, const float* d_kp2_xy, pm_match* d_good,
                                float* d_xy1, float* d_xy2, int32_t* d_n_good);
+/* The reference's own strong-match rule (main.cpp:49-69, what pm_filter_midpoint does on the host)
+ * in the same device-resident form: record i of d_m is d_m[i*k] (k = 1 for a 1-NN match list);
+ * d_minmax (may be NULL) receives minMatch / maxMatch as two doubles (main.cpp:58-59). */
+int pm_filter_midpoint_gather_dev(pm_ctx* ctx, const pm_match* d_m, int n, int k,
+                                  const float* d_kp1_xy, const float* d_kp2_xy, pm_match* d_good,
+                                  float* d_xy1, float* d_xy2, int32_t* d_n_good, double* d_minmax);
 /* Multi-GPU glue: concatenates `parts` padded blocks of `stride` points (d_counts[p] valid in
  * block p), e.g. the all-gathered per-rank survivors of a query-row-sharded matcher, into one
  * contiguous correspondence array in part order; *d_n_total = sum of counts. */

@@ -32,7 +32,7 @@ EXPORTS = [
     "pm_bf_knn_l2_f32", "pm_bf_knn_l2_f32_dev", "pm_bf_knn_hamming_u8", "pm_bf_knn_hamming_u8_dev",
     "pm_filter_midpoint", "pm_filter_ratio", "pm_match_indices", "pm_gather_points",
     "pm_format_match_list",
-    "pm_filter_ratio_gather_dev", "pm_concat_points_dev",
+    "pm_filter_ratio_gather_dev", "pm_filter_midpoint_gather_dev", "pm_concat_points_dev",
     "pm_ransac_fundamental", "pm_ransac_score_dev", "pm_ransac_score_devn", "pm_ransac_model_from_hyp",
     "pm_ransac_model_from_key_dev", "pm_ransac_run_dev",
     "pm_batch_create", "pm_batch_destroy", "pm_batch_run", "pm_host_register", "pm_host_unregister",
@@ -232,6 +232,13 @@ class Context:
                                                 C.c_void_p(dkp1_ptr), C.c_void_p(dkp2_ptr),
                                                 C.c_void_p(dgood_ptr), C.c_void_p(dxy1_ptr),
                                                 C.c_void_p(dxy2_ptr), C.c_void_p(dn_ptr)))
+
+    def filter_midpoint_gather_dev(self, dm_ptr, n, k, dkp1_ptr, dkp2_ptr, dgood_ptr, dxy1_ptr, dxy2_ptr, dn_ptr,
+                                   dminmax_ptr=0):
+        _check(lib().pm_filter_midpoint_gather_dev(self._h, C.c_void_p(dm_ptr), n, k, C.c_void_p(dkp1_ptr),
+                                                   C.c_void_p(dkp2_ptr), C.c_void_p(dgood_ptr), C.c_void_p(dxy1_ptr),
+                                                   C.c_void_p(dxy2_ptr), C.c_void_p(dn_ptr),
+                                                   C.c_void_p(dminmax_ptr or 0)))
 
     def concat_points_dev(self, dxy1_parts, dxy2_parts, dcounts, parts, stride, dxy1, dxy2, dn_total):
         _check(lib().pm_concat_points_dev(self._h, C.c_void_p(dxy1_parts), C.c_void_p(dxy2_parts),

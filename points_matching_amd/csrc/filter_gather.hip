@@ -20,23 +20,73 @@ constexpr int FG_ROWS = 256;
 constexpr int FG_MAX_BLOCKS = 4096;          // 1M query rows; more -> the caller is told so
 constexpr unsigned FG_SPIN_LIMIT = 200000u;
 
-__device__ __forceinline__ bool fg_keep(const pm_match* __restrict__ knn, int i, int k, float ratio, pm_match& best)
+enum { FG_RATIO = 0, FG_MIDPOINT = 1 };
+struct FgParam {
+    float ratio;       // FG_RATIO: d1 < ratio * d2
+    double cut;        // FG_MIDPOINT: (double)d < cut, cut = min + (max - min)/2 (main.cpp:65)
+};
+
+template <int MODE>
+__device__ __forceinline__ bool fg_keep(const pm_match* __restrict__ knn, int i, int k, const FgParam& prm, pm_match& best)
 {
     const uint4 a = *reinterpret_cast<const uint4*>(knn + static_cast<size_t>(i) * k);
-    const uint4 b = *reinterpret_cast<const uint4*>(knn + static_cast<size_t>(i) * k + 1);
     best.queryIdx = static_cast<int>(a.x); best.trainIdx = static_cast<int>(a.y);
     best.imgIdx = static_cast<int>(a.z);   best.distance = __uint_as_float(a.w);
-    const float rhs = ratio * __uint_as_float(b.w);
-    return static_cast<int>(a.y) >= 0 && static_cast<int>(b.y) >= 0 && best.distance < rhs;
+    if (MODE == FG_RATIO) {
+        const uint4 b = *reinterpret_cast<const uint4*>(knn + static_cast<size_t>(i) * k + 1);
+        const float rhs = prm.ratio * __uint_as_float(b.w);
+        return static_cast<int>(a.y) >= 0 && static_cast<int>(b.y) >= 0 && best.distance < rhs;
+    }
+    return static_cast<double>(best.distance) < prm.cut;
 }
 
+// order-preserving map float -> uint (negative values reversed, positives above them)
+__device__ __forceinline__ unsigned fg_ord(float f)
+{
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fg_unord(unsigned k)
+{
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+// main.cpp:49-56: minMatch starts at 1, maxMatch at 0, then min/max over the distances (NaN never
+// wins a comparison).  mm[0] = epoch-tagged max of ~ord(d) (the minimum), mm[1] = max of ord(d).
+__global__ __launch_bounds__(FG_ROWS) void midpoint_minmax(const pm_match* __restrict__ m, int n, int k,
+                                                           unsigned long long* __restrict__ mm, unsigned epoch)
+{
+    const int i = blockIdx.x * FG_ROWS + threadIdx.x;
+    float d = __uint_as_float(reinterpret_cast<const unsigned*>(m + static_cast<size_t>(i < n ? i : n - 1) * k)[3]);
+    const bool ok = i < n && d == d;
+    unsigned lo = fg_ord(1.0f), hi = fg_ord(0.0f);
+    if (ok) { const unsigned o = fg_ord(d); lo = o < lo ? o : lo; hi = o > hi ? o : hi; }
+    lo = pm::wave_min_u32(lo);
+    hi = pm::wave_max_u32(hi);
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned long long tag = static_cast<unsigned long long>(epoch) << 32;
+        atomicMax(&mm[0], tag | static_cast<unsigned>(~lo));
+        atomicMax(&mm[1], tag | hi);
+    }
+}
+
+template <int MODE>
 __global__ __launch_bounds__(FG_ROWS) void filter_ratio_gather(const pm_match* __restrict__ knn, int nq, int k,
                                                                float ratio, const float* __restrict__ kp1,
                                                                const float* __restrict__ kp2,
                                                                pm_match* __restrict__ good, float* __restrict__ xy1,
                                                                float* __restrict__ xy2, int* __restrict__ n_out,
-                                                               unsigned* __restrict__ blk_counts, unsigned epoch)
+                                                               unsigned* __restrict__ blk_counts, unsigned epoch,
+                                                               const unsigned long long* __restrict__ mm,
+                                                               double* __restrict__ minmax_out)
 {
+    FgParam prm{ratio, 0.0};
+    double lo_d = 1.0, hi_d = 0.0;
+    if (MODE == FG_MIDPOINT) {                     // the words were completed by midpoint_minmax (previous launch)
+        lo_d = static_cast<double>(fg_unord(~static_cast<unsigned>(mm[0])));
+        hi_d = static_cast<double>(fg_unord(static_cast<unsigned>(mm[1])));
+        prm.cut = lo_d + (hi_d - lo_d) / 2;
+    }
     __shared__ int wave_cnt[FG_ROWS / 64];
     __shared__ int wave_pre[FG_ROWS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -45,7 +95,7 @@ __global__ __launch_bounds__(FG_ROWS) void filter_ratio_gather(const pm_match* _
 
     // own row (clamped load, guard on the flag) and the keypoints it would carry
     pm_match best;
-    const bool keep = fg_keep(knn, i < nq ? i : nq - 1, k, ratio, best) && i < nq;
+    const bool keep = fg_keep<MODE>(knn, i < nq ? i : nq - 1, k, prm, best) && i < nq;
     float2 pa = {0.f, 0.f}, pb = {0.f, 0.f};
     if (kp1) {
         pa = *reinterpret_cast<const float2*>(kp1 + 2 * static_cast<size_t>(best.queryIdx));
@@ -76,7 +126,7 @@ __global__ __launch_bounds__(FG_ROWS) void filter_ratio_gather(const pm_match* _
             pm_match tmp;
             for (int r = 0; r < FG_ROWS; ++r) {
                 const int row = pb_ * FG_ROWS + r;
-                before += fg_keep(knn, row, k, ratio, tmp) ? 1 : 0;       // row < b*FG_ROWS <= nq
+                before += fg_keep<MODE>(knn, row, k, prm, tmp) ? 1 : 0;   // row < b*FG_ROWS <= nq
             }
         }
     }
@@ -101,6 +151,7 @@ __global__ __launch_bounds__(FG_ROWS) void filter_ratio_gather(const pm_match* _
         int tot = mine;
         for (int w = 0; w < FG_ROWS / 64; ++w) tot += wave_pre[w];
         *n_out = tot;
+        if (MODE == FG_MIDPOINT && minmax_out) { minmax_out[0] = lo_d; minmax_out[1] = hi_d; }
     }
 }
 
@@ -133,6 +184,27 @@ __global__ __launch_bounds__(256) void concat_points(const float* __restrict__ x
 
 }  // namespace
 
+namespace {
+
+int fg_prepare(pm_ctx* ctx, int nq, int* nblk)
+{
+    *nblk = (nq + FG_ROWS - 1) / FG_ROWS;
+    PM_REQUIRE(*nblk <= FG_MAX_BLOCKS, PM_E_UNSUPPORTED, "more than 1M query rows per compaction call");
+    if (!ctx->fg_counts) {
+        // [FG_MAX_BLOCKS] survivor counts + 2 x 64-bit min/max words (8-byte aligned: FG_MAX_BLOCKS is even)
+        PM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ctx->fg_counts), sizeof(unsigned) * (FG_MAX_BLOCKS + 4)));
+        PM_HIP_CHECK(hipMemsetAsync(ctx->fg_counts, 0, sizeof(unsigned) * (FG_MAX_BLOCKS + 4), ctx->stream));
+        ctx->fg_epoch = 0;
+    }
+    if (++ctx->fg_epoch >= (1u << 22)) {          // 22-bit tag: restart
+        PM_HIP_CHECK(hipMemsetAsync(ctx->fg_counts, 0, sizeof(unsigned) * (FG_MAX_BLOCKS + 4), ctx->stream));
+        ctx->fg_epoch = 1;
+    }
+    return PM_OK;
+}
+
+}  // namespace
+
 extern "C" int pm_filter_ratio_gather_dev(pm_ctx* ctx, const pm_match* d_knn, int nq, int k, float ratio,
                                           const float* d_kp1_xy, const float* d_kp2_xy, pm_match* d_good,
                                           float* d_xy1, float* d_xy2, int32_t* d_n_good)
@@ -148,19 +220,45 @@ extern "C" int pm_filter_ratio_gather_dev(pm_ctx* ctx, const pm_match* d_knn, in
         PM_HIP_CHECK(hipMemsetAsync(d_n_good, 0, sizeof(int32_t), ctx->stream));
         return PM_OK;
     }
-    const int nblk = (nq + FG_ROWS - 1) / FG_ROWS;
-    PM_REQUIRE(nblk <= FG_MAX_BLOCKS, PM_E_UNSUPPORTED, "more than 1M query rows per compaction call");
-    if (!ctx->fg_counts) {
-        PM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ctx->fg_counts), sizeof(unsigned) * FG_MAX_BLOCKS));
-        PM_HIP_CHECK(hipMemsetAsync(ctx->fg_counts, 0, sizeof(unsigned) * FG_MAX_BLOCKS, ctx->stream));
-        ctx->fg_epoch = 0;
+    int nblk = 0;
+    const int rc = fg_prepare(ctx, nq, &nblk);
+    if (rc != PM_OK) return rc;
+    hipLaunchKernelGGL(filter_ratio_gather<FG_RATIO>, dim3(nblk), dim3(FG_ROWS), 0, ctx->stream, d_knn, nq, k, ratio,
+                       d_kp1_xy, d_kp2_xy, d_good, d_xy1, d_xy2, d_n_good, ctx->fg_counts, ctx->fg_epoch, nullptr, nullptr);
+    PM_HIP_CHECK(hipGetLastError());
+    return PM_OK;
+}
+
+// The reference's own filter (main.cpp:49-69) in device-resident form: min/max scan, then the same
+// stable compaction with the predicate (double)d < min + (max - min)/2.
+extern "C" int pm_filter_midpoint_gather_dev(pm_ctx* ctx, const pm_match* d_m, int n, int k, const float* d_kp1_xy,
+                                             const float* d_kp2_xy, pm_match* d_good, float* d_xy1, float* d_xy2,
+                                             int32_t* d_n_good, double* d_minmax)
+{
+    PM_REQUIRE(ctx != nullptr && d_n_good != nullptr, PM_E_INVALID, "null argument");
+    PM_REQUIRE(n >= 0 && k >= 1, PM_E_INVALID, "need n >= 0, k >= 1");
+    PM_REQUIRE(n == 0 || (d_m && d_good), PM_E_INVALID, "null match buffers");
+    PM_REQUIRE((d_kp1_xy == nullptr) == (d_kp2_xy == nullptr), PM_E_INVALID, "give both keypoint arrays or none");
+    PM_REQUIRE(d_kp1_xy == nullptr || (d_xy1 && d_xy2), PM_E_INVALID, "null point outputs");
+    PM_HIP_CHECK(hipSetDevice(ctx->device));
+    pm::ScopedKernelTime t(ctx, "filter_gather");
+    if (n == 0) {
+        PM_HIP_CHECK(hipMemsetAsync(d_n_good, 0, sizeof(int32_t), ctx->stream));
+        if (d_minmax) {
+            const double init[2] = {1.0, 0.0};
+            PM_HIP_CHECK(hipMemcpyAsync(d_minmax, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+            PM_HIP_CHECK(hipStreamSynchronize(ctx->stream));       // `init` lives on this stack frame
+        }
+        return PM_OK;
     }
-    if (++ctx->fg_epoch >= (1u << 22)) {          // 22-bit tag: restart
-        PM_HIP_CHECK(hipMemsetAsync(ctx->fg_counts, 0, sizeof(unsigned) * FG_MAX_BLOCKS, ctx->stream));
-        ctx->fg_epoch = 1;
-    }
-    hipLaunchKernelGGL(filter_ratio_gather, dim3(nblk), dim3(FG_ROWS), 0, ctx->stream, d_knn, nq, k, ratio, d_kp1_xy,
-                       d_kp2_xy, d_good, d_xy1, d_xy2, d_n_good, ctx->fg_counts, ctx->fg_epoch);
+    int nblk = 0;
+    const int rc = fg_prepare(ctx, n, &nblk);
+    if (rc != PM_OK) return rc;
+    unsigned long long* mm = reinterpret_cast<unsigned long long*>(ctx->fg_counts + FG_MAX_BLOCKS);
+    hipLaunchKernelGGL(midpoint_minmax, dim3(nblk), dim3(FG_ROWS), 0, ctx->stream, d_m, n, k, mm, ctx->fg_epoch);
+    PM_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(filter_ratio_gather<FG_MIDPOINT>, dim3(nblk), dim3(FG_ROWS), 0, ctx->stream, d_m, n, k, 0.f,
+                       d_kp1_xy, d_kp2_xy, d_good, d_xy1, d_xy2, d_n_good, ctx->fg_counts, ctx->fg_epoch, mm, d_minmax);
     PM_HIP_CHECK(hipGetLastError());
     return PM_OK;
 }

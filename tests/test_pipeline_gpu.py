@@ -97,3 +97,42 @@ def test_knn_stats_report_refinement(ctx):
     st = ctx.knn_stats()
     ctx.knn_diag_enable(False)
     assert st["nonfinite"] == 0 and st["rescans"] < 32      # the MFMA route, not the re-scan, did the work
+
+
+@pytest.mark.parametrize("n,scale", [(1, 0.3), (255, 0.5), (256, 300.0), (257, 0.9), (5000, 0.7), (4097, 250.0)])
+def test_device_midpoint_filter_matches_the_reference_rule(ctx, n, scale):
+    """pm_filter_midpoint_gather_dev == the host restatement of main.cpp:49-69 (incl. the min = 1,
+    max = 0 start values: with SIFT-scale distances, all > 1, minMatch stays 1) + main.cpp:89-91."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(n)
+    m = np.zeros(n, pm.MATCH_DTYPE)
+    m["queryIdx"] = np.arange(n)
+    m["trainIdx"] = rng.integers(0, 777, n)
+    m["distance"] = (rng.random(n) * scale + (2.0 if scale > 1 else 0.0)).astype(np.float32)
+    if n > 300:
+        m["distance"][7] = np.nan                          # a NaN never wins a comparison (main.cpp:54-55, :65)
+        m["distance"][100:110] = m["distance"][100]        # ties
+    kp1 = rng.random((n, 2)).astype(np.float32) * 900
+    kp2 = rng.random((777, 2)).astype(np.float32) * 600
+    good_h, lo, hi = pm.api.filter_midpoint(m)
+    d_m = torch.from_numpy(m.view(np.int32).reshape(n, 4)).to(dev)
+    d_kp1, d_kp2 = torch.from_numpy(kp1).to(dev), torch.from_numpy(kp2).to(dev)
+    d_good = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    d_xy1 = torch.zeros((n, 2), dtype=torch.float32, device=dev)
+    d_xy2 = torch.zeros((n, 2), dtype=torch.float32, device=dev)
+    d_n = torch.zeros(1, dtype=torch.int32, device=dev)
+    d_mm = torch.zeros(2, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    for rep in range(2):                                   # the second call reuses the epoch-tagged words
+        ctx.filter_midpoint_gather_dev(d_m.data_ptr(), n, 1, d_kp1.data_ptr(), d_kp2.data_ptr(), d_good.data_ptr(),
+                                       d_xy1.data_ptr(), d_xy2.data_ptr(), d_n.data_ptr(), d_mm.data_ptr())
+        ctx.synchronize()
+        k = int(d_n.item())
+        assert k == good_h.size
+        got = d_good.cpu().numpy().view(pm.MATCH_DTYPE).reshape(-1)[:k]
+        assert (got["queryIdx"] == good_h["queryIdx"]).all() and (got["trainIdx"] == good_h["trainIdx"]).all()
+        assert (got["distance"].view(np.uint32) == good_h["distance"].view(np.uint32)).all()
+        assert d_mm.cpu().numpy().tolist() == [lo, hi]
+        assert np.array_equal(d_xy1.cpu().numpy()[:k], kp1[good_h["queryIdx"]])
+        assert np.array_equal(d_xy2.cpu().numpy()[:k], kp2[good_h["trainIdx"]])
