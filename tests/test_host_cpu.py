@@ -102,3 +102,22 @@ def test_key_helpers():
     k = api.ransac_key(1413, 5525)
     assert api.ransac_key_hyp(k) == 5525 and api.ransac_key_inliers(k) == 1413
     assert api.ransac_key(5, 10) > api.ransac_key(5, 11) > api.ransac_key(4, 0)   # more inliers, then lower id
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/pm.h is the drop-in boundary: it must compile as C99 (and C++11) with no torch / HIP types."""
+    import subprocess
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "pm.h"\n'
+                   "int main(void) { pm_ransac_params p = {0, 10, 1u, 1.0f, PM_ERR_SAMPSON};\n"
+                   "  pm_lmeds_params l = {0, 300, 7u}; pm_adaptive_params a = {2000, 0.99, 3.0f, 0, 1u};\n"
+                   "  pm_pair_job j = {0, 0, 0, 0, 1, 1}; (void)p; (void)l; (void)a; (void)j;\n"
+                   "  return (int)pm_ransac_key_inliers(pm_ransac_key(3u, 4u)) - 3; }\n")
+    inc = os.path.join(ROOT, "include")
+    for cmd in (["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror"],
+                ["g++", "-std=c++11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-x", "c++"]):
+        r = subprocess.run(cmd + ["-I", inc, "-c", str(src), "-o", str(tmp_path / "hdr.o")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    text = open(os.path.join(inc, "pm.h")).read()
+    includes = [ln.strip() for ln in text.splitlines() if ln.strip().startswith("#include")]
+    assert includes == ["#include <stddef.h>", "#include <stdint.h>"], includes
