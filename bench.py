@@ -121,7 +121,8 @@ def bench_c5(args, world, rank, local_rank, dev, multi, saved_stdout):
         "metric": "descriptor-pair distances/s (BF-L2 2-NN + ratio stage); RANSAC hypotheses/s in `ransac`",
         "value": pairs_per_s * n * n, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32 in/out; coarse pass f16xf16->f32 MFMA (exact for u8-valued data), refinement f32",
+        "dtype": "f32",
+        "dtype_note": "f32 in/out; coarse pass f16xf16->f32 MFMA (exact for u8-valued data), refinement f32",
         "data": "synthetic",
         "config": {"workload": "C5: batch of %d image pairs x (%d x %d SIFT-128 f32 BF-L2 2-NN + ratio 0.8 + %d-hypothesis "
                                "RANSAC-F), end to end incl. H2D/D2H from pinned host memory, %d lanes per GPU; pairs "
@@ -365,7 +366,11 @@ def main():
                   % ("Hamming" if hamming else "L2"),
         "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u8 bits; coarse pass i8xi8->i32 MFMA on +-1 expanded bits (exact), refinement u32 xor/popcount" if hamming else "f32 in/out; coarse pass f16xf16->f32 MFMA (exact for u8-valued data), refinement f32",
+        "dtype": "u8" if hamming else "f32",
+        "dtype_note": "u8 bit strings; coarse pass i8xi8->i32 MFMA on +-1 expanded bits (exact), refinement u32 xor/popcount"
+                      if hamming else ("f32 in/out; coarse pass f16xf16->f32 MFMA (exact for u8-valued data), refinement f32"
+                                       if knn_flags else "f32 in/out; coarse pass on f32-input MFMA (or the exact f16 one when the "
+                                                         "device finds the data integer-valued), refinement f32"),
         "data": "synthetic",
         "config": {"workload": "%s: %dx%d %s BF-%s 2-NN + ratio 0.8 + %d-hypothesis RANSAC-F (8-point, "
                                "Sampson, tau=1px) per image pair; N>1: query rows and hypothesis ids sharded"
