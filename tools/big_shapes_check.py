@@ -1,0 +1,30 @@
+"""Large / lopsided shapes against the oracle on the GPU box (not part of the test suite: ~1 minute of
+CPU oracle time).  python tools/big_shapes_check.py"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import points_matching_amd as pm
+from points_matching_amd import synth
+from oracle import pm_oracle as O
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from util import assert_matches_equal
+O.build()
+ctx = pm.Context(0)
+rng = np.random.default_rng(1)
+for (nq, nt, kind, flags) in [(600, 300000, "sift", 0), (600, 300000, "surf", 0), (70000, 1500, "sift", 4), (300, 70000, "sift", 4)]:
+    q, t, _ = (synth.sift_like if kind == "sift" else synth.surf_like)(nq, nt, 128, seed=nq + nt)
+    t0 = time.time(); got = ctx.bf_knn_l2(q, t, 2, flags); t1 = time.time()
+    want = O.bf_knn_l2(q, t, 2, nthreads=16)
+    assert_matches_equal(got, want, str((nq, nt, kind)))
+    print("L2", nq, nt, kind, "ok", round(t1 - t0, 3), "s incl. copies")
+q, t, _ = synth.orb_like(500, 300000, 32, seed=5)
+assert_matches_equal(ctx.bf_knn_hamming(q, t, 2), O.bf_knn_hamming(q, t, 2, nthreads=16), "ham big nt")
+q, t, _ = synth.orb_like(100000, 700, 32, seed=6)
+assert_matches_equal(ctx.bf_knn_hamming(q, t, 2), O.bf_knn_hamming(q, t, 2, nthreads=16), "ham big nq")
+print("hamming big ok")
+x1, x2, _, _ = synth.two_view(30000, seed=3, outlier_frac=0.4, noise_px=0.7)
+g = ctx.ransac_fundamental(x1, x2, 3000, 1.0, 5)
+w = O.ransac_fundamental(x1, x2, 3000, 1.0, 5, nthreads=16)
+assert g[0] == w[0] and g[4] == w[4] and (g[2] == w[2]).all() and (g[1].view(np.uint64) == w[1].view(np.uint64)).all()
+print("ransac n=30000 ok", g[3])
