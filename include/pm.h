@@ -65,9 +65,11 @@ int  pm_ctx_set_stream(pm_ctx* ctx, void* hip_stream);
 int  pm_ctx_synchronize(pm_ctx* ctx);
 /* Per-kernel timing with hipEvents on the context's stream.  enable!=0 starts collecting.
  * pm_ctx_timing_get: mean milliseconds and launch count of the named kernel since the last
- * pm_ctx_timing_reset (synchronises the stream).  Names: "knn_l2_mfma", "knn_l2_refine",
- * "knn_l2_exact", "knn_l2_prep", "knn_hamming", "ransac_solve", "ransac_score",
- * "ransac_select", "ransac_final". */
+ * pm_ctx_timing_reset (synchronises the stream).  Names: "knn_l2_prep", "knn_l2_mfma_f16",
+ * "knn_l2_mfma", "knn_l2_refine", "knn_l2_exact", "knn_hamming_expand", "knn_hamming_mfma_i8",
+ * "knn_hamming_refine", "knn_hamming", "knn_hamming_merge", "filter_gather", "concat_points",
+ * "ransac_solve", "ransac_score", "ransac_select", "ransac_final", "lmeds_solve", "lmeds_median",
+ * "lmeds_final", "fm_count". */
 int  pm_ctx_timing_enable(pm_ctx* ctx, int enable);
 int  pm_ctx_timing_reset(pm_ctx* ctx);
 int  pm_ctx_timing_get(pm_ctx* ctx, const char* kernel, double* mean_ms, int* launches);
@@ -106,7 +108,9 @@ int pm_bf_knn_l2_f32_dev(pm_ctx* ctx, const float* d_q, int nq, const float* d_t
                          int dim, int k, int flags, pm_match* d_out);
 
 /* Binary descriptors (ORB-256 = 32 bytes/row): Hamming distance, popcount of XOR.
- * `bytes` must be a multiple of 4.  Replaces main.cpp:46 for BASELINE config C4. */
+ * `bytes` must be a multiple of 4.  Replaces main.cpp:46 for BASELINE config C4.  32-byte
+ * descriptors with k <= 2 (16-byte-aligned device buffers) run on the matrix cores (+-1 expansion on
+ * i8 MFMA + popcount refinement), everything else on the integer VALU scan; same output. */
 int pm_bf_knn_hamming_u8(pm_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt,
                          int bytes, int k, pm_match* out);
 int pm_bf_knn_hamming_u8_dev(pm_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt,
