@@ -44,6 +44,23 @@ __device__ __forceinline__ void top4_insert(f32x4& c, float x)
     c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
 }
 
+// The two lane halves of a query column (lanes r and r + 32: rows 4h..4h+3 of every 8-row stripe) keep
+// separate lists while the sweep runs; at the end the half bit goes into bit 0 of every id and the two
+// sorted lists are merged into ONE list of 4 per (query, split) — half the candidate volume for the
+// refinement.  Once per kernel: four cross-half shuffles and four inserts.
+__device__ __forceinline__ void merge_halves(f32x4& cl, int h)
+{
+    f32x4 own, other;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        own[i] = __uint_as_float(__float_as_uint(cl[i]) | static_cast<unsigned>(h));
+        other[i] = __shfl_xor(own[i], 32, 64);
+    }
+    cl = own;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) top4_insert(cl, other[i]);
+}
+
 // GROUPED selection.  Registers 4g..4g+3 of an accumulator are four CONSECUTIVE train rows
 // (8g + 4*(lane>>5) + {0,1,2,3} of the 32-row block).  Only the group's largest w competes for the
 // list (2 VALU per 4 values: v_max3 + v_max), tagged with the GROUP id; the refinement
@@ -174,7 +191,7 @@ __device__ __forceinline__ void knn_tile_compute(float* __restrict__ Ts, int buf
             constexpr int NG = 4 * NB;
 #pragma unroll
             for (int g = (c == 0 ? 0 : (c - 1) * NG / (NCH - 1)); g < (c == 0 ? 0 : c * NG / (NCH - 1)); ++g)      // block g>>2, group g&3
-                top4_insert(cl, embed_lid(group_max(p[g >> 2], g & 3), keep_mask, pbase + static_cast<unsigned>(g)));
+                top4_insert(cl, embed_lid(group_max(p[g >> 2], g & 3), keep_mask, (pbase + static_cast<unsigned>(g)) << 1));
             // pin the selection to this chunk: without a use here hipcc sinks all of it below the
             // MFMA chain (in front of the barrier), where nothing hides it.
             asm volatile("" : "+v"(cl[0]), "+v"(cl[1]), "+v"(cl[2]), "+v"(cl[3]));
@@ -187,7 +204,7 @@ __device__ __forceinline__ void knn_select_all(const f32x16 (&p)[NB], unsigned p
 {
 #pragma unroll
     for (int g = 0; g < 4 * NB; ++g)
-        top4_insert(cl, embed_lid(group_max(p[g >> 2], g & 3), keep_mask, pbase + static_cast<unsigned>(g)));
+        top4_insert(cl, embed_lid(group_max(p[g >> 2], g & 3), keep_mask, (pbase + static_cast<unsigned>(g)) << 1));
 }
 
 #ifdef PM_ABL_NOBARRIER
@@ -268,8 +285,9 @@ __global__ __launch_bounds__(256, (TT == 64 ? 2 : 1)) void knn_l2_mfma(
         }
     }
 
-    if (qrow < nq) {
-        const size_t o = static_cast<size_t>(qrow) * slots + (blockIdx.y * 2 + h) * KNN_C;
+    merge_halves(cl, h);
+    if (qrow < nq && h == 0) {
+        const size_t o = static_cast<size_t>(qrow) * slots + blockIdx.y * KNN_C;
         *reinterpret_cast<f32x4*>(cand_val + o) = cl;
     }
 }
@@ -294,6 +312,7 @@ struct RouteF16 {
     static constexpr int ROW16 = H_ROW16;             // 16-byte units per global row
     static constexpr int LDS_ROW16 = H_LDS_ROW16;     // ... per LDS row (one pad slot)
     static constexpr int GPB = 4;                     // row groups per 32-row block and lane: groups of 4 rows
+    static constexpr bool MERGE = true;               // one list per (query, split): float ties are rare
     typedef f16x8 frag;
     typedef f32x16 acc;
     typedef f32x4 list;
@@ -310,6 +329,7 @@ struct RouteF16 {
     {
         top4_insert(cl, embed_lid(group_max(a, g), par, gid));
     }
+    static __device__ __forceinline__ void merge(list& cl, int h) { merge_halves(cl, h); }
 };
 
 struct RouteI8 {
@@ -317,6 +337,8 @@ struct RouteI8 {
     static constexpr int ROW16 = I8_ROW16;
     static constexpr int LDS_ROW16 = I8_LDS_ROW16;
     static constexpr int GPB = 2;                     // groups of 8 rows: the popcount refinement is cheap
+    static constexpr bool MERGE = false;              // integer distances tie all the time: a 4-deep merged list would
+                                                      // overflow (and force split re-scans) for most queries
     typedef i32x4 frag;
     typedef i32x16 acc;
     typedef i32x4 list;
@@ -334,11 +356,20 @@ struct RouteI8 {
         const int m = max(max(max(m0, m1), a[8 * g + 6]), a[8 * g + 7]);
         const int x = static_cast<int>((static_cast<unsigned>(m) << I8_SHIFT) | gid);   // v_lshl_or_b32
         (void)par;
+        insert(cl, x);
+    }
+    static __device__ __forceinline__ void insert(list& cl, int x)
+    {
         const int n0 = max(x, cl[0]);
         const int n1 = med3(x, cl[0], cl[1]);
         const int n2 = med3(x, cl[1], cl[2]);
         const int n3 = med3(x, cl[2], cl[3]);
         cl[0] = n0; cl[1] = n1; cl[2] = n2; cl[3] = n3;
+    }
+    static __device__ __forceinline__ void merge(list& cl, int h)     // MERGE == false: only tags the ids with the half
+    {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cl[i] = cl[i] == I8_EMPTY ? I8_EMPTY : (cl[i] | h);
     }
 };
 
@@ -403,7 +434,7 @@ __device__ __forceinline__ void h_block(const uint4* __restrict__ tb, const type
             constexpr int NGB = R::GPB * NQB;
 #pragma unroll
             for (int e = (c - 1) * NGB / (R::NCH - 1); e < c * NGB / (R::NCH - 1); ++e)   // query column e % NQB, group e / NQB
-                R::select(p[e % NQB], par, pbase + static_cast<unsigned>(e / NQB), cl[e % NQB], e / NQB);
+                R::select(p[e % NQB], par, (pbase + static_cast<unsigned>(e / NQB)) << 1, cl[e % NQB], e / NQB);
             if (NQB == 2)
                 asm volatile("" : "+v"(cl[0][0]), "+v"(cl[0][1]), "+v"(cl[0][2]), "+v"(cl[0][3]), "+v"(cl[NQB - 1][0]),
                              "+v"(cl[NQB - 1][1]), "+v"(cl[NQB - 1][2]), "+v"(cl[NQB - 1][3]));
@@ -494,12 +525,17 @@ __global__ __launch_bounds__(H_QB / (32 * NQB) * 64, (NQB == 2 ? 2 : 4)) void kn
 #pragma unroll
         for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
-            for (int g = 0; g < R::GPB; ++g) R::select(B[qb], par, lb + static_cast<unsigned>(g), cl[qb], g);
+            for (int g = 0; g < R::GPB; ++g) R::select(B[qb], par, (lb + static_cast<unsigned>(g)) << 1, cl[qb], g);
     }
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
         const int q = qbase + 32 * qb + r;
-        if (q < nq) cand_val[(static_cast<size_t>(q) * slots + (blockIdx.y * 2 + h) * KNN_C) / KNN_C] = cl[qb];
+        R::merge(cl[qb], h);
+        if (R::MERGE) {
+            if (q < nq && h == 0) cand_val[(static_cast<size_t>(q) * slots + blockIdx.y * KNN_C) / KNN_C] = cl[qb];
+        } else {
+            if (q < nq) cand_val[(static_cast<size_t>(q) * slots + (blockIdx.y * 2 + h) * KNN_C) / KNN_C] = cl[qb];
+        }
     }
 }
 

@@ -267,7 +267,7 @@ __device__ __forceinline__ int hamming256(const uint4 q0, const uint4 q1, const 
 }
 
 // One wave per query.  cand: [nq][slots] ints, sub-list s = entries 4s..4s+3 in descending order,
-// s = split*2 + lane half; entry = (dot << shift) | gid, gid = tile_in_split*8 + block*2 + group;
+// s = split*2 + lane half; entry = (dot << shift) | id, id = (tile_in_split*8 + block*2 + group) * 2 + lane half;
 // group (block, g, half hh) = rows 32*block + 16*g + 4*hh + {0,1,2,3, 8,9,10,11} of the tile.
 constexpr int HR_MAXE = 8;          // entries per lane: slots <= 512
 // NE = entries per lane actually needed (ceil(slots / 64) rounded up to 1, 2, 4 or 8): the per-entry
@@ -293,9 +293,9 @@ __global__ __launch_bounds__(256) void knn_hamming_refine(const uint32_t* __rest
         const int e = lane + 64 * i;
         v[i] = e < slots ? cand[static_cast<size_t>(q) * slots + e] : I8_EMPTY;
         dc[i] = v[i] == I8_EMPTY ? 0x7FFFFFF0 : ((I8_BITS - (v[i] >> shift)) >> 1);      // coarse (= exact) distance
-        const int gid = v[i] & gmask, sub = e >> 2;
-        const int last = ((sub >> 1) * tiles_per_split + (gid >> 3)) * H_TT + 32 * ((gid >> 1) & 3) + 16 * (gid & 1) +
-                         4 * (sub & 1) + 11;
+        const int gid2 = v[i] & gmask, gid = gid2 >> 1, split = e >> 3;
+        const int last = (split * tiles_per_split + (gid >> 3)) * H_TT + 32 * ((gid >> 1) & 3) + 16 * (gid & 1) +
+                         4 * (gid2 & 1) + 11;
         whole[i] = v[i] != I8_EMPTY && last < nt;
     }
     // tau = k-th smallest distance over the entries whose rows are all real (k distinct rows lie within
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void knn_hamming_refine(const uint32_t* __rest
         while (f) {                                          // rare
             const int src = __ffsll(static_cast<long long>(f)) - 1;
             f &= f - 1ull;
-            const int sub = (src + 64 * i) >> 2, split = sub >> 1, hh = sub & 1;
+            const int sub = (src + 64 * i) >> 2, split = sub >> 1, hh = sub & 1;      // the rows of that lane half
             for (int idx = lane; idx < tiles_per_split * 64; idx += 64) {
                 const int tile = idx >> 6, rem = idx & 63;
                 const int row = (split * tiles_per_split + tile) * H_TT + 32 * (rem >> 4) + 8 * ((rem >> 2) & 3) + 4 * hh +
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void knn_hamming_refine(const uint32_t* __rest
         const int t = base + lane;
         if (t < 8 * total) {
             const int ent = clist[wave][t >> 3];
-            const int gid = ent & 0xFFFF, sub = ent >> 16, split = sub >> 1, hh = sub & 1;
+            const int gid2 = ent & 0xFFFF, gid = gid2 >> 1, hh = gid2 & 1, split = ent >> 17;      // ent >> 16 = split*2 + half
             const int s8 = t & 7;
             const int row = (split * tiles_per_split + (gid >> 3)) * H_TT + 32 * ((gid >> 1) & 3) + 16 * (gid & 1) + 4 * hh +
                             8 * (s8 >> 2) + (s8 & 3);
@@ -383,7 +383,7 @@ int run_mfma(pm_ctx* ctx, const uint32_t* dq, int nq, const uint32_t* dt, int nt
     splits = (ntiles + tiles_per_split - 1) / tiles_per_split;
     const int slots = splits * 2 * KNN_C;
     constexpr int shift = I8_SHIFT;
-    if (tiles_per_split * (H_TT / 16) > (1 << shift)) return PM_OK;     // > 64k groups per lane stream: VALU route
+    if (tiles_per_split * (H_TT / 16) * 2 > (1 << shift)) return PM_OK; // > 64k (group, half) ids per split: VALU route
 
     const size_t cb = sizeof(int) * static_cast<size_t>(nq) * slots;
     const size_t qe = sizeof(uint4) * static_cast<size_t>(nq_pad) * I8_ROW16, te = sizeof(uint4) * static_cast<size_t>(nt_pad) * I8_ROW16;

@@ -276,7 +276,7 @@ __device__ __forceinline__ void best2_insert(Best2& b, uint64_t key, float d)
 // to a train row, and how wide the refinement window must be).
 struct KnnGeom {
     const float* cand;        // [nq][slots]
-    int slots;                // splits * 2 * KNN_C
+    int slots;                // splits * KNN_C
     int tiles_per_split;
     int rows_per_tile;        // 64 (f32 route) or 128 (f16 route); ids per tile = rows/2
     unsigned lid_mask;
@@ -381,8 +381,9 @@ __global__ __launch_bounds__(256) void knn_l2_refine(
         const int s = lane + 64 * i;
         const float w = s < slots ? cv[s] : -KNN_INF;
         const float v = w > -1.0e38f ? fmaf(-2.f, w, na) : KNN_INF;
-        const unsigned gid = __float_as_uint(w) & lid_mask;
-        const int split = s >> 3, hh = (s >> 2) & 1;          // s / (2*KNN_C), (s / KNN_C) & 1
+        const unsigned gid2 = __float_as_uint(w) & lid_mask;   // (group id << 1) | lane half
+        const unsigned gid = gid2 >> 1;
+        const int split = s >> 2, hh = static_cast<int>(gid2 & 1u);      // s / KNN_C
         const int tile = static_cast<int>(gid >> gshift), rem = static_cast<int>(gid & ((1u << gshift) - 1u));
         val[i] = v;
         row0[i] = (split * tiles_per_split + tile) * rows_per_tile + 32 * (rem >> 2) + 8 * (rem & 3) + 4 * hh;
@@ -407,8 +408,6 @@ __global__ __launch_bounds__(256) void knn_l2_refine(
     Best2 b{~0ull, ~0ull, KNN_INF, KNN_INF};
     if (!rescan) {
         const int grp = lane >> 3, l = lane & 7;
-        const int ids = rows_per_tile >> 1;                 // rows a lane sees per tile (a power of two)
-        const int ids_shift2 = 31 - __clz(ids);
         int total = 0;
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
@@ -426,14 +425,12 @@ __global__ __launch_bounds__(256) void knn_l2_refine(
             if (is_cand) clist[wave][total + __popcll(cand & ((1ull << lane) - 1ull))] = j;
             total += __popcll(cand);
             if (diag && lane == 0 && spilled) atomicAdd(&diag[0], static_cast<unsigned>(__popcll(spilled)));
-            while (spilled) {                               // wave-uniform, rare
-                const int sub = (64 * i + __ffsll(static_cast<long long>(spilled)) - 1) / KNN_C;
+            while (spilled) {                               // wave-uniform, rare: every row of that split
+                const int split = (64 * i + __ffsll(static_cast<long long>(spilled)) - 1) / KNN_C;
                 spilled &= spilled - 1ull;
-                const int split = sub >> 1, hh = sub & 1;
-                for (int lid = lane; lid < tiles_per_split * ids; lid += 64) {
-                    const int tile = lid >> ids_shift2, rem = lid & (ids - 1);
-                    const int row = (split * tiles_per_split + tile) * rows_per_tile + 32 * (rem >> 4) + (rem & 3) +
-                                    8 * ((rem & 15) >> 2) + 4 * hh;
+                const int row_begin = split * tiles_per_split * rows_per_tile;
+                for (int lid = lane; lid < tiles_per_split * rows_per_tile; lid += 64) {
+                    const int row = row_begin + lid;
                     if (row < nt) {
                         const float d = __builtin_sqrtf(
                             l2sqr_canonical<VEC4>(qp, T + static_cast<size_t>(row) * dim, dim));
@@ -718,10 +715,11 @@ extern "C" int pm_bf_knn_l2_f32_dev(pm_ctx* ctx, const float* dq, int nq, const 
         if (splits < 1) splits = 1;
         g32.tiles_per_split = (ntiles + splits - 1) / splits;
         splits32 = (ntiles + g32.tiles_per_split - 1) / g32.tiles_per_split;
-        g32.slots = splits32 * 2 * KNN_C;
+        g32.slots = splits32 * KNN_C;
         g32.rows_per_tile = TT;
-        // row-group id inside a lane's stream: tile_in_split*(TT/8) + block*4 + group, in the low mantissa bits
-        while ((1 << lid_bits32) < g32.tiles_per_split * (TT / 8)) ++lid_bits32;
+        // candidate id = (row-group id inside a lane's stream: tile_in_split*(TT/8) + block*4 + group) * 2 + lane half,
+        // in the low mantissa bits
+        while ((1 << lid_bits32) < g32.tiles_per_split * (TT / 8) * 2) ++lid_bits32;
         g32.lid_mask = (1u << lid_bits32) - 1u;
         // |coarse - canonical| <= (6*dim + 32) * 2^-24 * (||q||^2 + ||t||^2), plus the id truncation
         // 2^(bits-23) * (||q||^2 + 2||t||^2); see docs/SPEC.md S1b
@@ -734,17 +732,14 @@ extern "C" int pm_bf_knn_l2_f32_dev(pm_ctx* ctx, const float* dq, int nq, const 
         const int nqb = nq_pad / H_QB;
         const int ntiles = nt_pad / H_TT;
         int splits = (2 * ctx->n_cu + nqb - 1) / nqb;
-        // short sweeps: the refinement's cost grows with the number of candidate lists (C3: 16 splits ->
-        // 22.0 + 15.7 us coarse + refine, 8 splits -> 23.6 + 13.1), so one workgroup per CU is enough
-        if (splits >= 16 && (ntiles + splits - 1) / splits < 8) splits = (ctx->n_cu + nqb - 1) / nqb;
         if (splits > ntiles) splits = ntiles;
         if (splits > 64) splits = 64;
         if (splits < 1) splits = 1;
         g16.tiles_per_split = (ntiles + splits - 1) / splits;
         splits16 = (ntiles + g16.tiles_per_split - 1) / g16.tiles_per_split;
-        g16.slots = splits16 * 2 * KNN_C;
+        g16.slots = splits16 * KNN_C;
         g16.rows_per_tile = H_TT;
-        while ((1 << lid_bits16) < g16.tiles_per_split * (H_TT / 8)) ++lid_bits16;
+        while ((1 << lid_bits16) < g16.tiles_per_split * (H_TT / 8) * 2) ++lid_bits16;
         g16.lid_mask = (1u << lid_bits16) - 1u;
         g16.eps_coef = 0.f;           // integer data: the f16 products and f32 sums are exact
         g16.embed_coef = static_cast<float>(static_cast<double>(1u << lid_bits16) * 1.1920928955078125e-7 * 1.01);
