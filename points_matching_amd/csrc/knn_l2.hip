@@ -710,6 +710,9 @@ extern "C" int pm_bf_knn_l2_f32_dev(pm_ctx* ctx, const float* dq, int nq, const 
         const int nqb = (nq + QB - 1) / QB;
         const int ntiles = (nt + TT - 1) / TT;
         int splits = (2 * ctx->n_cu + nqb - 1) / nqb;
+        // at most 2048 train rows per split: the id embedded in a candidate costs mantissa bits, and with them
+        // the window widens (more candidates, overflowing lists -> split re-scans): 9-10 id bits at most
+        if (splits < (ntiles + 31) / 32) splits = (ntiles + 31) / 32;
         if (splits > ntiles) splits = ntiles;
         if (splits > 64) splits = 64;
         if (splits < 1) splits = 1;
@@ -732,6 +735,7 @@ extern "C" int pm_bf_knn_l2_f32_dev(pm_ctx* ctx, const float* dq, int nq, const 
         const int nqb = nq_pad / H_QB;
         const int ntiles = nt_pad / H_TT;
         int splits = (2 * ctx->n_cu + nqb - 1) / nqb;
+        if (splits < (ntiles + 15) / 16) splits = (ntiles + 15) / 16;          // <= 2048 rows per split (see above)
         if (splits > ntiles) splits = ntiles;
         if (splits > 64) splits = 64;
         if (splits < 1) splits = 1;
