@@ -196,3 +196,29 @@ def test_knn_randomised_shapes_values_and_routes(ctx, oracle):
         got = ctx.bf_knn_l2(q, t, k, flags)
         want = oracle.bf_knn_l2(q, t, k, nthreads=4)
         assert_matches_equal(got, want, "case %d: nq=%d nt=%d dim=%d k=%d fam=%d flags=%d" % (case, nq, nt, dim, k, fam, flags))
+
+
+@pytest.mark.parametrize("kind", ["sift", "surf"])
+def test_knn_32k_long_sweeps_slice_and_no_list_overflow(ctx, oracle, kind):
+    """32k x 32k: many query blocks -> few, long splits.  A 1k-query slice against the oracle, and the
+    refinement must not fall back to split re-scans (the id bits embedded in the candidates widen the
+    window; splits are capped at 2048 rows for that reason)."""
+    import torch
+    n = 32768
+    q, t, truth = (synth.sift_like if kind == "sift" else synth.surf_like)(n, n, 128, seed=0x32)
+    dev = torch.device("cuda", 0)
+    d_q, d_t = torch.from_numpy(q).to(dev), torch.from_numpy(t).to(dev)
+    d_out = torch.empty((n, 2, 4), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.knn_diag_enable(True)
+    ctx.bf_knn_l2_dev(d_q.data_ptr(), n, d_t.data_ptr(), n, 128, 2, d_out.data_ptr(), 0)
+    st = ctx.knn_stats()
+    ctx.knn_diag_enable(False)
+    got = d_out.cpu().numpy().view(pm.MATCH_DTYPE).reshape(n, 2)
+    sl = slice(5000, 6024)
+    want = oracle.bf_knn_l2(q[sl], t, 2, nthreads=8)
+    want["queryIdx"] += 5000
+    assert_matches_equal(got[sl], want, "32k slice " + kind)
+    assert st["rescans"] <= 2 and st["nonfinite"] == 0, st
+    planted = truth >= 0
+    assert (got["trainIdx"][planted, 0] == truth[planted]).mean() > 0.99
