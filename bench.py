@@ -140,6 +140,21 @@ def bench_c5(args, world, rank, local_rank, dev, multi, saved_stdout):
         dist.destroy_process_group()
 
 
+def launch_ranks(n):
+    """Parent of a multi-GPU run: never initialises the GPU, never execs; children are fresh processes."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    rc = subprocess.call(cmd, env=env)
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,6 +181,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: start the N ranks ourselves.  This parent has not
+    # imported torch or touched HIP; it only spawns `torch.distributed.run` (one fresh process per GPU),
+    # relays the children's stdout (rank 0 prints the JSON line) and exits with their status.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus)
 
     # Only the JSON line may reach stdout: RCCL prints a version banner to fd 1 when it initialises,
     # so fd 1 points at stderr until the result is ready.
@@ -197,7 +218,10 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    if multi:
+        world = dist.get_world_size()          # what the communicator actually saw: this is `n_gpus` in the JSON
 
     if args.workload == "c5":
         return bench_c5(args, world, rank, local_rank, dev, multi, saved_stdout)
@@ -225,21 +249,26 @@ def main():
     d_kp2 = torch.from_numpy(np.ascontiguousarray(w["kp2"])).to(dev)
     d_knn = torch.empty((nq, K, 4), dtype=torch.int32, device=dev)
     d_good = torch.empty((nq, 4), dtype=torch.int32, device=dev)
-    d_xy1 = torch.zeros((nq, 2), dtype=torch.float32, device=dev)
-    d_xy2 = torch.zeros((nq, 2), dtype=torch.float32, device=dev)
-    d_n = torch.zeros(1, dtype=torch.int32, device=dev)
+    # One contiguous "survivor block" per rank: [count (int32) + 3 pad words | xy1: nq x 2 f32 | xy2: nq x 2 f32].
+    # The filter writes straight into it, so the N>1 exchange before RANSAC is ONE all-gather of this block and
+    # RANSAC reads the gathered blocks through a pm_points_view (no concatenation pass).
+    blk_words = 4 + 4 * nq
+    d_blk = torch.zeros(blk_words, dtype=torch.float32, device=dev)
+    d_n = d_blk[0:1].view(torch.int32)
+    d_xy1 = d_blk[4:4 + 2 * nq].view(nq, 2)
+    d_xy2 = d_blk[4 + 2 * nq:].view(nq, 2)
     d_key = torch.zeros(1, dtype=torch.int64, device=dev)
     n_all_max = nq * world
     d_F = torch.zeros(9, dtype=torch.float64, device=dev)
     d_mask = torch.zeros(n_all_max, dtype=torch.uint8, device=dev)
     d_ninl = torch.zeros(1, dtype=torch.int32, device=dev)
+    d_ntot = torch.zeros(1, dtype=torch.int32, device=dev)
     if multi:
-        g_xy1 = torch.zeros((world, nq, 2), dtype=torch.float32, device=dev)
-        g_xy2 = torch.zeros((world, nq, 2), dtype=torch.float32, device=dev)
-        g_n = torch.zeros(world, dtype=torch.int32, device=dev)
-        a_xy1 = torch.zeros((n_all_max, 2), dtype=torch.float32, device=dev)
-        a_xy2 = torch.zeros((n_all_max, 2), dtype=torch.float32, device=dev)
-        a_n = torch.zeros(1, dtype=torch.int32, device=dev)
+        g_blk = torch.zeros((world, blk_words), dtype=torch.float32, device=dev)
+        d_rec = torch.zeros(10, dtype=torch.float64, device=dev)             # pm_ransac_record: key + F[9]
+        g_rec = torch.zeros((world, 10), dtype=torch.float64, device=dev)
+        view = pm.api.PointsView(g_blk.data_ptr() + 16, g_blk.data_ptr() + 16 + 8 * nq, g_blk.data_ptr(), world, nq,
+                                 blk_words, blk_words, 0)
     hb, he = shard.hyp_shard(H, rank, world)
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
@@ -256,20 +285,13 @@ def main():
         if e:
             e[1].record(stream)
         if multi:
-            shard.gather_blocks(d_xy1, d_xy2, d_n, g_xy1, g_xy2, g_n)
-            ctx.concat_points_dev(g_xy1.data_ptr(), g_xy2.data_ptr(), g_n.data_ptr(), world, nq,
-                                  a_xy1.data_ptr(), a_xy2.data_ptr(), a_n.data_ptr())
-            x1, x2, nn = a_xy1, a_xy2, a_n
+            dist.all_gather_into_tensor(g_blk.view(-1), d_blk)             # exchange 1: survivor blocks
+            ctx.ransac_shard_parts_dev(view, hb, he, thresh, seed, d_rec.data_ptr())
+            dist.all_gather_into_tensor(g_rec.view(-1), d_rec)             # exchange 2: 80-byte (key, F) records
+            ctx.ransac_finish_parts_dev(view, thresh, g_rec.data_ptr(), world, d_key.data_ptr(), d_F.data_ptr(),
+                                        d_mask.data_ptr(), n_all_max, d_ninl.data_ptr(), d_ntot.data_ptr())
         else:
-            x1, x2, nn = d_xy1, d_xy2, d_n
-        if multi:
-            ctx.ransac_score_devn(x1.data_ptr(), x2.data_ptr(), n_all_max, nn.data_ptr(), hb, he, thresh, seed,
-                                  d_key.data_ptr())
-            shard.reduce_key(d_key)                            # the single 8-byte exchange
-            ctx.ransac_model_from_key_dev(x1.data_ptr(), x2.data_ptr(), n_all_max, nn.data_ptr(), thresh, seed,
-                                          d_key.data_ptr(), d_F.data_ptr(), d_mask.data_ptr(), d_ninl.data_ptr())
-        else:
-            ctx.ransac_run_dev(x1.data_ptr(), x2.data_ptr(), n_all_max, nn.data_ptr(), hb, he, thresh, seed,
+            ctx.ransac_run_dev(d_xy1.data_ptr(), d_xy2.data_ptr(), nq, d_n.data_ptr(), hb, he, thresh, seed,
                                d_key.data_ptr(), d_F.data_ptr(), d_mask.data_ptr(), d_ninl.data_ptr())
         if e:
             e[2].record(stream)
@@ -296,7 +318,7 @@ def main():
         wall, match_ms, rest_ms = [float(x) for x in tt.tolist()]
     ms_per_step = wall / args.steps * 1e3
 
-    n_m = int((a_n if multi else d_n).item())
+    n_m = int((d_ntot if multi else d_n).item())
     key = int(d_key.item())
     n_inl = int(d_ninl.item())
 
@@ -310,7 +332,7 @@ def main():
     kern = {}
     for name in ("knn_l2_prep", "knn_l2_mfma_f16", "knn_l2_mfma", "knn_l2_refine", "knn_hamming_expand",
                  "knn_hamming_mfma_i8", "knn_hamming_refine", "knn_hamming", "knn_hamming_merge", "filter_gather", "ransac_solve", "ransac_score",
-                 "ransac_select", "ransac_final", "concat_points"):
+                 "ransac_select", "ransac_final", "concat_points", "ransac_fused", "ransac_finish"):
         ms, cnt = ctx.timing_get(name)
         if cnt:
             kern[name] = round(ms * 1e3, 2)           # microseconds
@@ -343,8 +365,14 @@ def main():
         want = (O.bf_knn_hamming if hamming else O.bf_knn_l2)(w["q"][rows], w["t"], K, nthreads=8)
         ok = (got["trainIdx"][rows] == want["trainIdx"]).all() and \
              (got["distance"][rows].view(np.uint32) == want["distance"].view(np.uint32)).all()
-        xs1 = (a_xy1 if multi else d_xy1)[:n_m].cpu().numpy()
-        xs2 = (a_xy2 if multi else d_xy2)[:n_m].cpu().numpy()
+        if multi:                                  # the concatenation the view stands for, done here for the checker only
+            gb = g_blk.cpu()
+            cnt = gb[:, 0:1].view(torch.int32).reshape(-1).tolist()
+            xs1 = np.concatenate([gb[p, 4:4 + 2 * nq].view(nq, 2)[:cnt[p]].numpy() for p in range(world)])
+            xs2 = np.concatenate([gb[p, 4 + 2 * nq:].view(nq, 2)[:cnt[p]].numpy() for p in range(world)])
+        else:
+            xs1 = d_xy1[:n_m].cpu().numpy()
+            xs2 = d_xy2[:n_m].cpu().numpy()
         rc, F_o, mask_o, ninl_o, key_o = O.ransac_fundamental(xs1, xs2, H, thresh, seed, nthreads=8)
         ok = ok and key_o == key and ninl_o == n_inl and (mask_o == d_mask[:n_m].cpu().numpy()).all() \
             and (F_o.reshape(9).view(np.uint64) == d_F.cpu().numpy().view(np.uint64)).all()
@@ -433,10 +461,13 @@ def main():
                                      "kernel_us": round(f32_route_us, 2),
                                      "traffic": pmc_traffic("c3_f32:knn_l2_mfma", nq, nt),
                                      "dtype": "f32-input MFMA (v_mfma_f32_32x32x2_f32): coarse route for general floats"}
-    if "ransac_score" in kern and n_m:
+    rk = "ransac_fused" if "ransac_fused" in kern else "ransac_score"
+    if rk in kern and n_m:
         flops = 34.0 * n_m * (he - hb)
-        ach = flops / (kern["ransac_score"] * 1e-6) / 1e12
-        out["roofline_ransac"] = {"kernel": "ransac_score", "bound": "valu-f32", "achieved": ach,
+        ach = flops / (kern[rk] * 1e-6) / 1e12
+        out["roofline_ransac"] = {"kernel": rk + (" (sample + solve + score + pick + mask in one launch; the fp64 solves are "
+                                                  "not credited)" if rk == "ransac_fused" else ""),
+                                  "bound": "valu-f32", "achieved": ach,
                                   "peak": PEAK_F32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_VALU_TFLOPS,
                                   "flops_per_pair": 34, "n_matches": n_m, "traffic": None}
 

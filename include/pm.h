@@ -68,7 +68,7 @@ int  pm_ctx_synchronize(pm_ctx* ctx);
  * pm_ctx_timing_reset (synchronises the stream).  Names: "knn_l2_prep", "knn_l2_mfma_f16",
  * "knn_l2_mfma", "knn_l2_refine", "knn_l2_exact", "knn_hamming_expand", "knn_hamming_mfma_i8",
  * "knn_hamming_refine", "knn_hamming", "knn_hamming_merge", "filter_gather", "concat_points",
- * "ransac_solve", "ransac_score", "ransac_select", "ransac_final", "lmeds_solve", "lmeds_median",
+ * "ransac_fused", "ransac_finish", "ransac_solve", "ransac_score", "ransac_select", "ransac_final", "lmeds_solve", "lmeds_median",
  * "lmeds_final", "fm_count". */
 int  pm_ctx_timing_enable(pm_ctx* ctx, int enable);
 int  pm_ctx_timing_reset(pm_ctx* ctx);
@@ -78,6 +78,17 @@ int  pm_ctx_timing_get(pm_ctx* ctx, const char* kernel, double* mean_ms, int* la
  * was seen; pm_ctx_knn_stats returns the values of the last such call (synchronises). */
 int  pm_ctx_knn_diag_enable(pm_ctx* ctx, int enable);
 int  pm_ctx_knn_stats(pm_ctx* ctx, int* rescans, int* nonfinite);
+/* Explicit per-context switches for tests and A/B timing (the library reads no environment variables).
+ * Every option defaults to 0 = automatic; a value outside an option's range is PM_E_INVALID. */
+enum {
+    PM_OPT_RANSAC_PATH    = 1,  /* 1: hypothesis-per-lane kernels (solve + score launches), 2: one-launch kernel  */
+    PM_OPT_SCORE_OPERANDS = 2,  /* hypothesis-per-lane scorer: 1 LDS-staged points, 2 scalar-operand pair records */
+    PM_OPT_HAMMING_ROUTE  = 3,  /* 1: integer-VALU scan, 2: matrix-core route with 64-bit refinement keys          */
+    PM_OPT_KNN_F16_WAVES  = 4,  /* f16/i8 coarse kernel: 1 = 8 waves x 32 queries, 2 = 4 waves x 64 queries        */
+    PM_OPT_COUNT_         = 8
+};
+int  pm_ctx_set_option(pm_ctx* ctx, int option, int value);
+int  pm_ctx_get_option(pm_ctx* ctx, int option, int* value);
 const char* pm_last_error(void);       /* thread-local text of the last PM_E_HIP / PM_E_* */
 const char* pm_status_string(int status);
 int  pm_version(void);                 /* major*100 + minor */
@@ -209,6 +220,41 @@ int pm_ransac_model_from_key_dev(pm_ctx* ctx, const float* d_xy1, const float* d
 int pm_ransac_model_from_hyp(pm_ctx* ctx, const float* xy1, const float* xy2, int n,
                              const pm_ransac_params* p, int64_t hyp, double F[9],
                              uint8_t* mask, int* n_inliers);
+/* ---- one-launch and sharded forms over a correspondence VIEW --------------------------------------
+ * A view names the correspondences without copying them: `parts` blocks of up to `cap` points, part p
+ * starting at xy1 + p*pitch_xy / xy2 + p*pitch_xy (floats) and holding counts[p*pitch_cnt] points
+ * (device-side, clamped to [0, cap]; counts == NULL: every part is full).  Correspondence i of the run is
+ * the i-th point in part order.  parts = 1 is a plain array, optionally with a device-side count.  This is
+ * how the all-gathered survivor blocks of a query-row-sharded matcher feed RANSAC on every
+ * rank without a concatenation pass. */
+#define PM_MAX_PARTS 64
+typedef struct pm_points_view {
+    const float*   xy1;
+    const float*   xy2;
+    const int32_t* counts;
+    int32_t parts;
+    int32_t cap;
+    int64_t pitch_xy;
+    int32_t pitch_cnt;
+    int32_t reserved;
+} pm_points_view;
+/* What a shard contributes to the multi-GPU exchange: its best key and the fp64 model behind it.  The
+ * global winner is the record with the largest key — an arg-max all-reduce, carried as one 80-byte
+ * all-gather (RCCL has no user-defined reduction); no rank re-solves anything. */
+typedef struct pm_ransac_record {
+    uint64_t key;       /* pm_ransac_key of the shard's winner, 0 if it has no valid model */
+    double   F[9];
+} pm_ransac_record;
+/* Sharded run, ONE launch: sample + solve + score ids [hyp_begin, hyp_end) over the view, write the
+ * shard's record to *d_record (device). */
+int pm_ransac_shard_parts_dev(pm_ctx* ctx, const pm_points_view* view, const pm_ransac_params* p,
+                              pm_ransac_record* d_record);
+/* After the exchange: winner among d_records[0..n_records), its F (9 doubles, may be NULL), inlier mask
+ * over the view (d_mask[0..mask_len), zero beyond the correspondence count), inlier count and (optional)
+ * the correspondence count itself.  Only thresh_px and error_kind of *p are used. */
+int pm_ransac_finish_parts_dev(pm_ctx* ctx, const pm_points_view* view, const pm_ransac_params* p,
+                               const pm_ransac_record* d_records, int n_records, uint64_t* d_key, double* d_F,
+                               uint8_t* d_mask, int mask_len, int32_t* d_n_inliers, int32_t* d_n_total);
 /* key helpers */
 static inline uint64_t pm_ransac_key(uint32_t inliers, uint32_t hyp) {
     return ((uint64_t)inliers << 32) | (uint64_t)(0xFFFFFFFFu - hyp);

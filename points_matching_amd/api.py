@@ -34,7 +34,8 @@ EXPORTS = [
     "pm_format_match_list",
     "pm_filter_ratio_gather_dev", "pm_filter_midpoint_gather_dev", "pm_concat_points_dev",
     "pm_ransac_fundamental", "pm_ransac_score_dev", "pm_ransac_score_devn", "pm_ransac_model_from_hyp",
-    "pm_ransac_model_from_key_dev", "pm_ransac_run_dev",
+    "pm_ransac_model_from_key_dev", "pm_ransac_run_dev", "pm_ransac_shard_parts_dev", "pm_ransac_finish_parts_dev",
+    "pm_ctx_set_option", "pm_ctx_get_option",
     "pm_batch_create", "pm_batch_destroy", "pm_batch_run", "pm_host_register", "pm_host_unregister",
     "pm_lmeds_fundamental", "pm_lmeds_fundamental_dev", "pm_lmeds_default_iters", "pm_ransac7_adaptive",
     "pm_epipolar_residuals", "pm_f_scale_f33", "pm_epilines", "pm_epiline_endpoints",
@@ -50,6 +51,17 @@ class PmError(RuntimeError):
 class RansacParams(C.Structure):
     _fields_ = [("hyp_begin", C.c_int64), ("hyp_end", C.c_int64), ("seed", C.c_uint64),
                 ("thresh_px", C.c_float), ("error_kind", C.c_int32)]
+
+
+class PointsView(C.Structure):
+    """pm_points_view: `parts` padded blocks of correspondences with device-side counts (include/pm.h)."""
+    _fields_ = [("xy1", C.c_void_p), ("xy2", C.c_void_p), ("counts", C.c_void_p), ("parts", C.c_int32),
+                ("cap", C.c_int32), ("pitch_xy", C.c_int64), ("pitch_cnt", C.c_int32), ("reserved", C.c_int32)]
+
+
+RANSAC_RECORD_DTYPE = np.dtype([("key", "<u8"), ("F", "<f8", (9,))])       # pm_ransac_record, 80 bytes
+PM_MAX_PARTS = 64
+PM_OPT_RANSAC_PATH, PM_OPT_SCORE_OPERANDS, PM_OPT_HAMMING_ROUTE, PM_OPT_KNN_F16_WAVES = 1, 2, 3, 4
 
 
 _lib = None
@@ -217,6 +229,25 @@ class Context:
         ms, n = C.c_double(), C.c_int()
         _check(lib().pm_ctx_timing_get(self._h, name.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def set_option(self, option, value):
+        _check(lib().pm_ctx_set_option(self._h, option, value))
+
+    def get_option(self, option):
+        v = C.c_int()
+        _check(lib().pm_ctx_get_option(self._h, option, C.byref(v)))
+        return v.value
+
+    def ransac_shard_parts_dev(self, view, hyp_begin, hyp_end, thresh_px, seed, drec_ptr, kind=PM_ERR_SAMPSON):
+        prm = RansacParams(hyp_begin, hyp_end, seed, thresh_px, kind)
+        _check(lib().pm_ransac_shard_parts_dev(self._h, C.byref(view), C.byref(prm), C.c_void_p(drec_ptr)))
+
+    def ransac_finish_parts_dev(self, view, thresh_px, drecs_ptr, n_records, dkey_ptr, dF_ptr, dmask_ptr, mask_len,
+                                dninl_ptr, dntotal_ptr=0, kind=PM_ERR_SAMPSON):
+        prm = RansacParams(0, 0, 0, thresh_px, kind)
+        _check(lib().pm_ransac_finish_parts_dev(self._h, C.byref(view), C.byref(prm), C.c_void_p(drecs_ptr), n_records,
+                                                C.c_void_p(dkey_ptr or 0), C.c_void_p(dF_ptr or 0), C.c_void_p(dmask_ptr),
+                                                mask_len, C.c_void_p(dninl_ptr or 0), C.c_void_p(dntotal_ptr or 0)))
 
     def knn_diag_enable(self, on=True):
         _check(lib().pm_ctx_knn_diag_enable(self._h, int(on)))

@@ -4,8 +4,6 @@
 //
 // Built with -ffinite-math-only (see knn_shared.hpp).  Nothing in this file decides a result bit:
 // the coarse values only nominate candidate rows for the canonical refinement.
-#include <cstdlib>
-
 #include "knn_shared.hpp"
 
 namespace pm_knn {
@@ -585,9 +583,9 @@ int launch_rows288(pm_ctx* ctx, const char* name, const void* Qh, const void* Th
                    unsigned epoch, int mode)
 {
     const size_t lds = sizeof(uint4) * 2 * H_TT * R::LDS_ROW16;
-    static const int nqb_env = [] { const char* e = getenv("PM_KNN_F16_NQB"); return e ? atoi(e) : 0; }();
     // few tiles per workgroup: the 8-wave form covers latency better; long sweeps: the 4-wave form halves LDS reads
-    const int nqb = nqb_env == 1 || nqb_env == 2 ? nqb_env : (tiles_per_split <= 8 ? 1 : 2);
+    const int nqb_opt = ctx->opts[PM_OPT_KNN_F16_WAVES];
+    const int nqb = nqb_opt ? nqb_opt : (tiles_per_split <= 8 ? 1 : 2);
     static bool attr_done_dev[PM_MAX_DEVICES] = {};          // the attribute is per device (and per template instance)
     bool& attr_done = attr_done_dev[ctx->device];
     if (!attr_done) {

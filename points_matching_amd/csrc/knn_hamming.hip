@@ -443,10 +443,9 @@ extern "C" int pm_bf_knn_hamming_u8_dev(pm_ctx* ctx, const uint8_t* dq, int nq, 
     const uint32_t* q32 = reinterpret_cast<const uint32_t*>(dq);
     const uint32_t* t32 = reinterpret_cast<const uint32_t*>(dt);
     const int nw = bytes / 4;
-    // tests / A-B timing: "valu" pins the VALU scan, "wide" the 64-bit-key refinement of the matrix-core route
-    const char* route_env = getenv("PM_HAMMING_ROUTE");
-    const bool force_valu = route_env && route_env[0] == 'v';
-    const bool wide_keys = route_env && route_env[0] == 'w';
+    // PM_OPT_HAMMING_ROUTE (tests / A-B timing): 1 pins the VALU scan, 2 the 64-bit-key refinement of the matrix-core route
+    const bool force_valu = ctx->opts[PM_OPT_HAMMING_ROUTE] == 1;
+    const bool wide_keys = ctx->opts[PM_OPT_HAMMING_ROUTE] == 2;
     if (bytes * 8 == I8_BITS && k <= 2 && nt >= 1 && !force_valu &&
         (reinterpret_cast<uintptr_t>(dq) & 15) == 0 && (reinterpret_cast<uintptr_t>(dt) & 15) == 0) {
         bool done = false;

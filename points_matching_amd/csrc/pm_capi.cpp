@@ -167,6 +167,7 @@ int pm_ctx_destroy(pm_ctx* ctx)
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->knn_stats) (void)hipFree(ctx->knn_stats);
     if (ctx->fg_counts) (void)hipFree(ctx->fg_counts);
+    if (ctx->sync_words) (void)hipFree(ctx->sync_words);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -218,6 +219,23 @@ int pm_ctx_timing_get(pm_ctx* ctx, const char* kernel, double* mean_ms, int* lau
     }
     if (mean_ms) *mean_ms = ms;
     if (launches) *launches = n;
+    return PM_OK;
+}
+
+int pm_ctx_set_option(pm_ctx* ctx, int option, int value)
+{
+    PM_REQUIRE(ctx != nullptr, PM_E_INVALID, "ctx is null");
+    PM_REQUIRE(option >= 1 && option < PM_OPT_COUNT_, PM_E_INVALID, "unknown option");
+    PM_REQUIRE(value >= 0 && value <= 2, PM_E_INVALID, "option value out of range (0 = automatic, 1, 2)");
+    ctx->opts[option] = value;
+    return PM_OK;
+}
+
+int pm_ctx_get_option(pm_ctx* ctx, int option, int* value)
+{
+    PM_REQUIRE(ctx != nullptr && value != nullptr, PM_E_INVALID, "null argument");
+    PM_REQUIRE(option >= 1 && option < PM_OPT_COUNT_, PM_E_INVALID, "unknown option");
+    *value = ctx->opts[option];
     return PM_OK;
 }
 

@@ -70,6 +70,9 @@ struct pm_ctx {
     // stable compaction: epoch-tagged per-block survivor counts
     unsigned* fg_counts = nullptr;
     unsigned fg_epoch = 0;
+    // arrival tickets / counters of the one-launch RANSAC kernels; every launch returns them to zero
+    int* sync_words = nullptr;
+    int opts[PM_OPT_COUNT_] = {};          // pm_ctx_set_option
 };
 
 namespace pm {

@@ -1,0 +1,468 @@
+// ransac_fused.hip — RANSAC-F in ONE launch on gfx950 (MI355X): sample + normalised 8-point solve + Sampson scoring
+// of every hypothesis against every correspondence + winner + inlier mask.  Replaces
+// `cv::findFundamentalMat(Mat(selPoints1), Mat(selPoints2), ...)` (main.cpp:95-98) with the estimator
+// BASELINE.json names (docs/SPEC.md S6-S9).
+//
+// Mapping (MI355X-first: the correspondences are scored out of registers):
+//   * a workgroup (4 waves) owns `hb` consecutive hypothesis ids and ALL correspondences: lane = correspondence
+//     pair (two points per packed-f32 instruction), 2*PPT2 points per thread = a tile of 2560 correspondences
+//     (config C3: one tile, loaded once); longer sets are walked tile by tile, every tile against all hb models;
+//   * solve phase: lane s < hb samples and solves hypothesis s (fp64, SPEC S7) and leaves the f32 model in LDS;
+//   * score phase: the model of hypothesis s is a wave-wide LDS broadcast, every lane tests its own points
+//     (v_pk_fma_f32), the verdicts leave the VALU as a v_cmp mask and are counted on the SCALAR unit
+//     (s_bcnt1_i32_b64 of the wavefront ballot) — no atomics, no LDS traffic per point;
+//   * the 4 partial counts per hypothesis meet in LDS, the workgroup's best key = (inliers << 32) | ~id and the
+//     fp64 model behind it go to the workgroup's slot (write-through stores), one ticket per workgroup;
+//   * the workgroup that draws the last ticket scans the slots, publishes the winner's stored fp64 model and
+//     writes the inlier mask straight from its registers (local run), or emits the 80-byte (key, F) record a
+//     multi-GPU run exchanges (sharded run: one all-gather, then pm_ransac_finish_parts_dev on every rank).
+// The correspondences may be given as `parts` padded blocks with device-side counts (the all-gathered survivors
+// of a query-row-sharded matcher): the view is resolved while loading, no concatenation pass exists.
+#include "ransac_core.hpp"
+#include "ransac_internal.hpp"
+
+namespace pm_ransac {
+namespace {
+
+constexpr int RF_THREADS = 256;
+constexpr int RF_PTS_PER_SLOT = 2 * RF_THREADS;      // points covered by one register slot (pair) of every thread
+constexpr int RF_PPT2 = 5;                           // register slots per thread: tiles of 2560 correspondences
+
+struct RfSlot {                   // one per workgroup, 128 B apart (never shares a line with another writer)
+    unsigned long long key;
+    double F[9];
+    unsigned long long pad[6];
+};
+static_assert(sizeof(RfSlot) == 128, "slot stride");
+
+struct RfOut {
+    int shard;                    // 0: finish here (key, F, mask, count); 1: emit the record only
+    unsigned long long* key;      // local
+    double* F;                    // local, may be null
+    uint8_t* mask;                // local
+    int mask_len;                 // local: bytes of `mask` (zero beyond n)
+    int* n_inliers;               // local, may be null
+    FinalOut* fo;                 // local, may be null (host entry point reads it back)
+    pm_ransac_record* rec;        // shard
+};
+
+// ---- correspondence view -------------------------------------------------------------------------------------
+// offs[p] = first global index of part p, offs[parts] = n.  One wave computes it (lane p <-> part p).
+__device__ __forceinline__ void view_offsets(const pm_points_view& v, int* __restrict__ offs, int tid)
+{
+    if (tid < 64) {
+        int c = 0;
+        if (tid < v.parts) {
+            c = v.cap;
+            if (v.counts) {
+                const int raw = v.counts[static_cast<size_t>(tid) * v.pitch_cnt];
+                c = raw < 0 ? 0 : (raw > v.cap ? v.cap : raw);
+            }
+        }
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o, 64);
+            if (tid >= o) incl += up;
+        }
+        if (tid < v.parts) offs[tid] = incl - c;
+        if (tid == v.parts - 1) offs[v.parts] = incl;
+    }
+}
+
+// point i of the concatenated order (i < n)
+__device__ __forceinline__ void view_point(const pm_points_view& v, const int* __restrict__ offs, int i, float2& a, float2& b)
+{
+    int p = 0;
+    while (p + 1 < v.parts && i >= offs[p + 1]) ++p;          // parts <= 64; 1 for a contiguous array
+    const size_t e = static_cast<size_t>(p) * static_cast<size_t>(v.pitch_xy) + 2 * static_cast<size_t>(i - offs[p]);
+    a = *reinterpret_cast<const float2*>(v.xy1 + e);
+    b = *reinterpret_cast<const float2*>(v.xy2 + e);
+}
+
+__device__ __forceinline__ bool hyp_model_view(const pm_points_view& v, const int* __restrict__ offs, int n, uint64_t seed,
+                                               uint64_t h, double (&F)[9])
+{
+    int idx[8];
+    sample8(seed, h, n, idx);
+    double x1[8], y1[8], x2[8], y2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float2 a, b;
+        view_point(v, offs, idx[i], a, b);
+        x1[i] = static_cast<double>(a.x); y1[i] = static_cast<double>(a.y);
+        x2[i] = static_cast<double>(b.x); y2[i] = static_cast<double>(b.y);
+    }
+    return solve8(x1, y1, x2, y2, F);
+}
+
+__device__ __forceinline__ unsigned long long wg_max_u64(unsigned long long key, unsigned long long* __restrict__ wk, int tid)
+{
+    key = pm::wave_max_u64(key);
+    __syncthreads();                                   // wk may still be read from an earlier use
+    if ((tid & 63) == 0) wk[tid >> 6] = key;
+    __syncthreads();
+    unsigned long long k = wk[0];
+#pragma unroll
+    for (int w = 1; w < RF_THREADS / 64; ++w) k = wk[w] > k ? wk[w] : k;
+    return k;
+}
+
+// ---- the kernel ------------------------------------------------------------------------------------------------
+template <int KIND, int PPT2>
+__global__ __launch_bounds__(RF_THREADS) void ransac_fused(pm_points_view v, uint64_t seed, int64_t hyp_begin, int nh, int hb,
+                                                           float thr2, RfSlot* __restrict__ slots, int* __restrict__ ticket,
+                                                           RfOut out)
+{
+    __shared__ __attribute__((aligned(16))) float s_mdl[RF_HB_MAX][12];    // f32 model + valid flag of hypothesis s
+    __shared__ double s_m64[RF_HB_MAX][9];
+    __shared__ int s_cnt[RF_THREADS / 64][RF_HB_MAX];
+    __shared__ int s_offs[PM_MAX_PARTS + 1];
+    __shared__ unsigned long long s_wk[RF_THREADS / 64];
+    __shared__ double s_F64[9];
+    __shared__ int s_role;
+    __shared__ int s_wc[RF_THREADS / 64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    view_offsets(v, s_offs, tid);
+    __syncthreads();
+    const int n = s_offs[v.parts];
+
+    // ---- correspondences -> registers, one tile of RF_TILE points at a time: slot k of thread t holds points
+    // base + 2*(k*256 + t) and +1 as packed pairs (x_a, x_b), (y_a, y_b), (x'_a, x'_b), (y'_a, y'_b); points >= n
+    // are NaN (never inliers)
+    constexpr int RF_TILE = RF_PTS_PER_SLOT * PPT2;
+    const int ntiles = n > RF_TILE ? (n + RF_TILE - 1) / RF_TILE : 1;
+    f32x2 X[PPT2], Y[PPT2], XP[PPT2], YP[PPT2];
+    const float nanv = __builtin_nanf("");
+    auto load_tile = [&](int t) -> int {
+        const int base = t * RF_TILE;
+        int kmax = (n - base + RF_PTS_PER_SLOT - 1) / RF_PTS_PER_SLOT;
+        kmax = kmax < 0 ? 0 : (kmax > PPT2 ? PPT2 : kmax);
+#pragma unroll
+        for (int k = 0; k < PPT2; ++k) {
+            X[k] = f32x2{nanv, nanv}; Y[k] = X[k]; XP[k] = X[k]; YP[k] = X[k];
+            if (k < kmax) {                                      // workgroup-uniform
+                const int i0 = base + 2 * (k * RF_THREADS + tid);
+                float2 a0 = {nanv, nanv}, b0 = a0, a1 = a0, b1 = a0;
+                if (i0 < n) view_point(v, s_offs, i0, a0, b0);
+                if (i0 + 1 < n) view_point(v, s_offs, i0 + 1, a1, b1);
+                X[k] = f32x2{a0.x, a1.x}; Y[k] = f32x2{a0.y, a1.y};
+                XP[k] = f32x2{b0.x, b1.x}; YP[k] = f32x2{b0.y, b1.y};
+            }
+        }
+        return kmax;
+    };
+    int kmax = load_tile(0);
+
+    // ---- solve: lane s solves hypothesis h0 + s (SPEC S6, S7); models stay in LDS
+    const int h0 = static_cast<int>(blockIdx.x) * hb;
+    const int hcount = nh - h0 < hb ? nh - h0 : hb;
+    if (tid < hcount) {
+        double F[9];
+        bool ok = false;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) F[i] = 0.0;
+        if (n >= 8) ok = hyp_model_view(v, s_offs, n, seed, static_cast<uint64_t>(hyp_begin + h0 + tid), F);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { s_mdl[tid][i] = static_cast<float>(F[i]); s_m64[tid][i] = F[i]; }
+        s_mdl[tid][9] = ok ? 1.f : 0.f;
+        s_mdl[tid][10] = 0.f; s_mdl[tid][11] = 0.f;
+    }
+    __syncthreads();
+
+    // ---- score: model = LDS broadcast, lane = its own points, count = popcount of the wavefront ballot (SALU)
+    for (int t = 0; t < ntiles; ++t) {
+        if (t > 0) kmax = load_tile(t);
+        f32x4v m0 = *reinterpret_cast<const f32x4v*>(&s_mdl[0][0]);
+        f32x4v m1 = *reinterpret_cast<const f32x4v*>(&s_mdl[0][4]);
+        float m2 = s_mdl[0][8];
+        for (int s = 0; s < hcount; ++s) {
+            const float f[9] = {m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3], m2};
+            const int sn = s + 1 < hcount ? s + 1 : s;       // next model requested before this one is scored
+            m0 = *reinterpret_cast<const f32x4v*>(&s_mdl[sn][0]);
+            m1 = *reinterpret_cast<const f32x4v*>(&s_mdl[sn][4]);
+            m2 = s_mdl[sn][8];
+            int c = 0;
+#pragma unroll
+            for (int k = 0; k < PPT2; ++k) {
+                if (k < kmax) {
+                    bool ia, ib;
+                    inlier32_x2_flags<KIND>(f, X[k], Y[k], XP[k], YP[k], thr2, ia, ib);
+                    c += __popcll(__ballot(ia)) + __popcll(__ballot(ib));
+                }
+            }
+            if (lane == 0) s_cnt[wave][s] = t == 0 ? c : s_cnt[wave][s] + c;
+        }
+    }
+    __syncthreads();
+
+    // ---- the workgroup's best key (SPEC S9: most inliers, then lowest id) and its slot
+    unsigned long long key = 0ull;
+    if (tid < hcount && s_mdl[tid][9] != 0.f) {
+        int c = 0;
+#pragma unroll
+        for (int w = 0; w < RF_THREADS / 64; ++w) c += s_cnt[w][tid];
+        key = (static_cast<unsigned long long>(static_cast<uint32_t>(c)) << 32) |
+              static_cast<unsigned long long>(0xFFFFFFFFu - static_cast<uint32_t>(hyp_begin + h0 + tid));
+    }
+    const unsigned long long kbest = wg_max_u64(key, s_wk, tid);
+    if (wave == 0) {
+        const int sb = kbest ? static_cast<int>(static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(kbest)) - hyp_begin) - h0 : 0;
+        RfSlot* sl = slots + blockIdx.x;
+        if (lane < 9) __hip_atomic_store(&sl->F[lane], kbest ? s_m64[sb][lane] : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 9) __hip_atomic_store(&sl->key, kbest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the slot is written through before the ticket is drawn
+        if (lane == 0) {
+            const int tk = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_role = tk == static_cast<int>(gridDim.x) - 1 ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    if (s_role == 0) return;
+
+    // ---- last workgroup: every slot is complete.  Winner = max key over the slots.
+    if (tid == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    unsigned long long kb = 0ull;
+    for (int j = tid; j < static_cast<int>(gridDim.x); j += RF_THREADS) {
+        const unsigned long long kj = __hip_atomic_load(&slots[j].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        kb = kj > kb ? kj : kb;
+    }
+    const unsigned long long kwin = wg_max_u64(kb, s_wk, tid);
+    const bool ok = kwin != 0ull && n >= 8;
+    if (tid < 9) {
+        const int owner = ok ? static_cast<int>((static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(kwin)) - hyp_begin) / hb) : 0;
+        const double fv = __hip_atomic_load(&slots[owner].F[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_F64[tid] = ok ? fv : 0.0;
+    }
+    __syncthreads();
+    if (out.shard) {
+        if (tid < 9) out.rec->F[tid] = s_F64[tid];
+        if (tid == 9) out.rec->key = ok ? kwin : 0ull;
+        return;
+    }
+    if (tid < 9) {
+        if (out.F) out.F[tid] = s_F64[tid];
+        if (out.fo) { out.fo->F[tid] = s_F64[tid]; out.fo->F32[tid] = static_cast<float>(s_F64[tid]); }
+    }
+    if (tid == 9) {
+        *out.key = ok ? kwin : 0ull;
+        if (out.fo) out.fo->valid = ok ? 1 : 0;
+    }
+    float fw[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) fw[i] = static_cast<float>(s_F64[i]);
+    int mine = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        if (ntiles > 1) kmax = load_tile(t);                 // a single tile is still in the registers
+#pragma unroll
+        for (int k = 0; k < PPT2; ++k) {
+            if (k < kmax) {
+                bool ia, ib;
+                inlier32_x2_flags<KIND>(fw, X[k], Y[k], XP[k], YP[k], thr2, ia, ib);
+                ia = ia && ok; ib = ib && ok;
+                const int i0 = t * RF_TILE + 2 * (k * RF_THREADS + tid);
+                if (i0 < out.mask_len) out.mask[i0] = ia ? 1 : 0;
+                if (i0 + 1 < out.mask_len) out.mask[i0 + 1] = ib ? 1 : 0;
+                mine += __popcll(__ballot(ia)) + __popcll(__ballot(ib));     // wave-uniform
+            }
+        }
+    }
+    const int covered = n > 0 ? (n + RF_PTS_PER_SLOT - 1) / RF_PTS_PER_SLOT * RF_PTS_PER_SLOT : 0;
+    for (int i = covered + tid; i < out.mask_len; i += RF_THREADS) out.mask[i] = 0;
+    if (lane == 0) s_wc[wave] = mine;
+    __syncthreads();
+    if (tid == 0) {
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < RF_THREADS / 64; ++w) tot += s_wc[w];
+        if (out.n_inliers) *out.n_inliers = tot;
+        if (out.fo) out.fo->n_inliers = tot;
+    }
+}
+
+// ---- finish of a sharded run: winner among the gathered records, its mask over the viewed correspondences -------
+// sync[0] = arrival ticket, sync[1] = inlier counter; both return to 0 at the end of the launch.
+template <int KIND>
+__global__ __launch_bounds__(RF_THREADS) void ransac_finish(pm_points_view v, const pm_ransac_record* __restrict__ recs, int nrec,
+                                                            float thr2, unsigned long long* __restrict__ key_out,
+                                                            double* __restrict__ F_out, uint8_t* __restrict__ mask, int mask_len,
+                                                            int* __restrict__ n_inl_out, int* __restrict__ n_total_out,
+                                                            int* __restrict__ sync)
+{
+    __shared__ int s_offs[PM_MAX_PARTS + 1];
+    __shared__ unsigned long long s_wk[RF_THREADS / 64];
+    __shared__ int s_wc[RF_THREADS / 64];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    view_offsets(v, s_offs, tid);
+    unsigned long long kb = 0ull;
+    for (int j = tid; j < nrec; j += RF_THREADS) { const unsigned long long kj = recs[j].key; kb = kj > kb ? kj : kb; }
+    const unsigned long long kwin = wg_max_u64(kb, s_wk, tid);          // (its barriers also publish s_offs)
+    const int n = s_offs[v.parts];
+    const bool ok = kwin != 0ull && n >= 8;
+    int owner = 0;
+    for (int j = 0; j < nrec; ++j) owner = recs[j].key == kwin ? j : owner;   // keys of distinct ids differ
+    float fw[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) fw[i] = ok ? static_cast<float>(recs[owner].F[i]) : 0.f;
+    if (blockIdx.x == 0) {
+        if (tid < 9 && F_out) F_out[tid] = ok ? recs[owner].F[tid] : 0.0;
+        if (tid == 9 && key_out) *key_out = ok ? kwin : 0ull;
+        if (tid == 10 && n_total_out) *n_total_out = n;
+    }
+    int mine = 0;
+    for (int i = static_cast<int>(blockIdx.x) * RF_THREADS + tid; i < mask_len; i += static_cast<int>(gridDim.x) * RF_THREADS) {
+        bool in = false;
+        if (i < n && ok) {
+            float2 a, b;
+            view_point(v, s_offs, i, a, b);
+            in = inlier32<KIND>(fw, a.x, a.y, b.x, b.y, thr2);
+        }
+        mask[i] = in ? 1 : 0;
+        mine += in ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if (lane == 0) s_wc[wave] = mine;
+    __syncthreads();
+    if (tid == 0) {
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < RF_THREADS / 64; ++w) tot += s_wc[w];
+        if (tot) __hip_atomic_fetch_add(&sync[1], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int tk = __hip_atomic_fetch_add(&sync[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = tk == static_cast<int>(gridDim.x) - 1 ? 1 : 0;
+        if (s_last) {
+            const int all = __hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (n_inl_out) *n_inl_out = all;
+            __hip_atomic_store(&sync[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sync[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+int check_view(const pm_points_view* v)
+{
+    PM_REQUIRE(v != nullptr && v->xy1 && v->xy2, PM_E_INVALID, "null correspondence view");
+    PM_REQUIRE(v->parts >= 1 && v->parts <= PM_MAX_PARTS && v->cap >= 1, PM_E_INVALID, "need 1 <= parts <= 64, cap >= 1");
+    PM_REQUIRE(v->parts == 1 || (v->pitch_xy >= 2LL * v->cap), PM_E_INVALID, "pitch_xy smaller than a part");
+    PM_REQUIRE(static_cast<long long>(v->parts) * v->cap <= 0x7FFFFFFFLL, PM_E_INVALID, "view too large");
+    return PM_OK;
+}
+
+int sync_words(pm_ctx* ctx, int** out)
+{
+    if (!ctx->sync_words) {
+        PM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ctx->sync_words), 256));
+        PM_HIP_CHECK(hipMemsetAsync(ctx->sync_words, 0, 256, ctx->stream));
+    }
+    *out = ctx->sync_words;
+    return PM_OK;
+}
+
+}  // namespace
+
+// Hypothesis ids per workgroup: whole rounds of one workgroup per CU, at most RF_HB_MAX ids each.
+int fused_hb(const pm_ctx* ctx, long long nh)
+{
+    const long long per_round = static_cast<long long>(ctx->n_cu) * RF_HB_MAX;
+    const long long rounds = (nh + per_round - 1) / per_round;
+    long long hb = (nh + ctx->n_cu * rounds - 1) / (ctx->n_cu * rounds);
+    if (hb < 1) hb = 1;
+    if (hb > RF_HB_MAX) hb = RF_HB_MAX;
+    return static_cast<int>(hb);
+}
+
+size_t fused_scratch_bytes(const pm_ctx* ctx, const pm_ransac_params* p)
+{
+    const long long nh = p->hyp_end - p->hyp_begin;
+    const int hb = fused_hb(ctx, nh);
+    const long long nwg = (nh + hb - 1) / hb;
+    return pm::align_up(sizeof(RfSlot) * static_cast<size_t>(nwg > 0 ? nwg : 1), 256) + pm::align_up(sizeof(FinalOut), 256) + 512;
+}
+
+// Enqueue the one-launch run.  The arena must already be reserved for fused_scratch_bytes(); it is carved here.
+// shard != 0: only *rec is written.  Otherwise key / F / mask[mask_len] / n_inliers (F, n_inliers, fo_out optional).
+int fused_launch(pm_ctx* ctx, const pm_points_view& v, const pm_ransac_params* p, int shard, pm_ransac_record* d_rec,
+                 unsigned long long* d_key, double* d_F, uint8_t* d_mask, int mask_len, int* d_ninl, FinalOut** fo_out)
+{
+    const long long nh = p->hyp_end - p->hyp_begin;
+    const long long cap_total = static_cast<long long>(v.parts) * v.cap;
+    PM_REQUIRE(nh >= 1, PM_E_INVALID, "fused_launch: empty hypothesis range");
+    const int hb = fused_hb(ctx, nh);
+    const int nwg = static_cast<int>((nh + hb - 1) / hb);
+    RfSlot* slots = static_cast<RfSlot*>(pm::arena_take(ctx, sizeof(RfSlot) * static_cast<size_t>(nwg)));
+    FinalOut* fo = static_cast<FinalOut*>(pm::arena_take(ctx, sizeof(FinalOut)));
+    PM_REQUIRE(slots && fo, PM_E_NOMEM, "scratch arena too small");
+    int* sync = nullptr;
+    int rc = sync_words(ctx, &sync);
+    if (rc != PM_OK) return rc;
+    RfOut out{};
+    out.shard = shard;
+    out.key = d_key; out.F = d_F; out.mask = d_mask; out.mask_len = mask_len; out.n_inliers = d_ninl;
+    out.fo = fo_out ? fo : nullptr;
+    out.rec = d_rec;
+    if (fo_out) *fo_out = fo;
+    const float thr2 = p->thresh_px * p->thresh_px;
+    pm::ScopedKernelTime t(ctx, "ransac_fused");
+    // 2*RF_PPT2 points per thread: a 2560-point tile (config C3 fits one); small capacities take the 2-slot build
+#define PM_RF(KIND_, PPT2_)                                                                                              \
+    hipLaunchKernelGGL((ransac_fused<KIND_, PPT2_>), dim3(nwg), dim3(RF_THREADS), 0, ctx->stream, v, p->seed, p->hyp_begin, \
+                       static_cast<int>(nh), hb, thr2, slots, sync, out)
+    const bool small = cap_total <= 2 * RF_PTS_PER_SLOT;
+    if (p->error_kind == PM_ERR_SAMPSON) { if (small) PM_RF(PM_ERR_SAMPSON, 2); else PM_RF(PM_ERR_SAMPSON, RF_PPT2); }
+    else { if (small) PM_RF(PM_ERR_SYM_EPIPOLAR, 2); else PM_RF(PM_ERR_SYM_EPIPOLAR, RF_PPT2); }
+#undef PM_RF
+    PM_HIP_CHECK(hipGetLastError());
+    return PM_OK;
+}
+
+}  // namespace pm_ransac
+
+using namespace pm_ransac;
+
+extern "C" int pm_ransac_shard_parts_dev(pm_ctx* ctx, const pm_points_view* view, const pm_ransac_params* p,
+                                         pm_ransac_record* d_record)
+{
+    PM_REQUIRE(ctx != nullptr && d_record != nullptr && p != nullptr, PM_E_INVALID, "null argument");
+    int rc = check_view(view);
+    if (rc != PM_OK) return rc;
+    PM_REQUIRE(p->hyp_begin >= 0 && p->hyp_end > p->hyp_begin && p->hyp_end <= 0x100000000LL, PM_E_INVALID,
+               "hypothesis ids must satisfy 0 <= begin < end <= 2^32");
+    PM_REQUIRE(p->error_kind == PM_ERR_SAMPSON || p->error_kind == PM_ERR_SYM_EPIPOLAR, PM_E_INVALID, "unknown error_kind");
+    PM_HIP_CHECK(hipSetDevice(ctx->device));
+    rc = pm::arena_reserve(ctx, fused_scratch_bytes(ctx, p) + 1024);
+    if (rc != PM_OK) return rc;
+    pm::arena_reset(ctx);
+    return fused_launch(ctx, *view, p, 1, d_record, nullptr, nullptr, nullptr, 0, nullptr, nullptr);
+}
+
+extern "C" int pm_ransac_finish_parts_dev(pm_ctx* ctx, const pm_points_view* view, const pm_ransac_params* p,
+                                          const pm_ransac_record* d_records, int n_records, uint64_t* d_key, double* d_F,
+                                          uint8_t* d_mask, int mask_len, int32_t* d_n_inliers, int32_t* d_n_total)
+{
+    PM_REQUIRE(ctx != nullptr && p != nullptr && d_records != nullptr && d_mask != nullptr, PM_E_INVALID, "null argument");
+    PM_REQUIRE(n_records >= 1 && mask_len >= 0, PM_E_INVALID, "need n_records >= 1, mask_len >= 0");
+    int rc = check_view(view);
+    if (rc != PM_OK) return rc;
+    PM_REQUIRE(p->error_kind == PM_ERR_SAMPSON || p->error_kind == PM_ERR_SYM_EPIPOLAR, PM_E_INVALID, "unknown error_kind");
+    PM_HIP_CHECK(hipSetDevice(ctx->device));
+    int* sync = nullptr;
+    rc = sync_words(ctx, &sync);
+    if (rc != PM_OK) return rc;
+    const float thr2 = p->thresh_px * p->thresh_px;
+    int blocks = (mask_len + 8 * RF_THREADS - 1) / (8 * RF_THREADS);
+    blocks = blocks < 1 ? 1 : (blocks > 64 ? 64 : blocks);
+    pm::ScopedKernelTime t(ctx, "ransac_finish");
+    unsigned long long* key = reinterpret_cast<unsigned long long*>(d_key);
+    if (p->error_kind == PM_ERR_SAMPSON)
+        hipLaunchKernelGGL(ransac_finish<PM_ERR_SAMPSON>, dim3(blocks), dim3(RF_THREADS), 0, ctx->stream, *view, d_records,
+                           n_records, thr2, key, d_F, d_mask, mask_len, d_n_inliers, d_n_total, sync + 2);
+    else
+        hipLaunchKernelGGL(ransac_finish<PM_ERR_SYM_EPIPOLAR>, dim3(blocks), dim3(RF_THREADS), 0, ctx->stream, *view, d_records,
+                           n_records, thr2, key, d_F, d_mask, mask_len, d_n_inliers, d_n_total, sync + 2);
+    PM_HIP_CHECK(hipGetLastError());
+    return PM_OK;
+}

@@ -64,14 +64,16 @@ def _requery(m, off):
 
 # ---- matrix-core (i8) route: 256-bit descriptors, k <= 2 -------------------------------------
 @pytest.mark.parametrize("nq,nt,k", [(700, 1000, 2), (257, 129, 1), (5, 128, 2), (1030, 4100, 2), (64, 2, 2)])
-def test_hamming_i8_route_matches_valu_route_and_oracle(ctx, oracle, nq, nt, k, monkeypatch):
+def test_hamming_i8_route_matches_valu_route_and_oracle(ctx, oracle, nq, nt, k):
     q, t, _ = synth.orb_like(nq, nt, 32, seed=7 * nq + nt)
     got = ctx.bf_knn_hamming(q, t, k)
-    monkeypatch.setenv("PM_HAMMING_ROUTE", "valu")
-    valu = ctx.bf_knn_hamming(q, t, k)
-    monkeypatch.setenv("PM_HAMMING_ROUTE", "wide")          # 64-bit keys (what >= 2^23 train rows would take)
-    wide = ctx.bf_knn_hamming(q, t, k)
-    monkeypatch.delenv("PM_HAMMING_ROUTE")
+    try:
+        ctx.set_option(pm.api.PM_OPT_HAMMING_ROUTE, 1)      # integer-VALU scan
+        valu = ctx.bf_knn_hamming(q, t, k)
+        ctx.set_option(pm.api.PM_OPT_HAMMING_ROUTE, 2)      # 64-bit keys (what >= 2^23 train rows would take)
+        wide = ctx.bf_knn_hamming(q, t, k)
+    finally:
+        ctx.set_option(pm.api.PM_OPT_HAMMING_ROUTE, 0)
     assert_matches_equal(got, valu, "i8 vs valu")
     assert_matches_equal(got, wide, "32-bit vs 64-bit keys")
     assert_matches_equal(got, oracle.bf_knn_hamming(q, t, k), "i8 vs oracle")

@@ -17,6 +17,15 @@ pytestmark = pytest.mark.gpu
 F_TOL = 0.0
 
 
+@pytest.fixture(autouse=True, params=["one-launch", "per-lane"])
+def ransac_path(request, ctx):
+    """Every test of this module runs on both device paths: the one-launch kernel (ransac_fused.hip, the default
+    for <= 10240 correspondences) and the hypothesis-per-lane solve + score launches (ransac.hip)."""
+    ctx.set_option(pm.api.PM_OPT_RANSAC_PATH, 2 if request.param == "one-launch" else 1)
+    yield request.param
+    ctx.set_option(pm.api.PM_OPT_RANSAC_PATH, 0)
+
+
 def _same(got, want, what):
     rc_g, F_g, mask_g, n_g, key_g = got
     rc_w, F_w, mask_w, n_w, key_w = want
@@ -45,15 +54,18 @@ def test_ransac_parity(ctx, oracle, n, iters, out_frac, noise, kind):
 
 @pytest.mark.parametrize("n,iters", [(8, 64), (9, 100), (130, 700), (1001, 3000), (2300, 1500)])
 @pytest.mark.parametrize("kind", [PM_ERR_SAMPSON, PM_ERR_SYM_EPIPOLAR])
-def test_ransac_scalar_operand_scorer_same_bits(ctx, oracle, n, iters, kind, monkeypatch):
+def test_ransac_scalar_operand_scorer_same_bits(ctx, oracle, n, iters, kind):
     """Both scorers (LDS-staged and scalar-operand pair records; the library picks by shard size)
     give the oracle's key / mask / F; odd counts exercise the NaN-padded last record."""
     x1, x2, _, _ = synth.two_view(n, seed=3 * n + iters, outlier_frac=0.3, noise_px=0.5)
     want = oracle.ransac_fundamental(x1, x2, iters, 1.0, 0x5EED, kind, nthreads=8)
-    for smem in ("1", "0"):
-        monkeypatch.setenv("PM_SCORE_SMEM", smem)
-        _same(ctx.ransac_fundamental(x1, x2, iters, 1.0, 0x5EED, kind), want, str((n, iters, kind, smem)))
-    monkeypatch.delenv("PM_SCORE_SMEM")
+    ctx.set_option(pm.api.PM_OPT_RANSAC_PATH, 1)           # the hypothesis-per-lane kernels
+    try:
+        for operands in (2, 1):
+            ctx.set_option(pm.api.PM_OPT_SCORE_OPERANDS, operands)
+            _same(ctx.ransac_fundamental(x1, x2, iters, 1.0, 0x5EED, kind), want, str((n, iters, kind, operands)))
+    finally:
+        ctx.set_option(pm.api.PM_OPT_SCORE_OPERANDS, 0)
 
 
 def test_ransac_every_hypothesis_model_matches(ctx, oracle):
