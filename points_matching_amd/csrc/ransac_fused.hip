@@ -27,6 +27,7 @@ namespace {
 constexpr int RF_THREADS = 256;
 constexpr int RF_PTS_PER_SLOT = 2 * RF_THREADS;      // points covered by one register slot (pair) of every thread
 constexpr int RF_PPT2 = 5;                           // register slots per thread: tiles of 2560 correspondences
+static_assert(RF_PPT2 <= 5, "score_tile is instantiated for 1..5 slots");
 
 struct RfSlot {                   // one per workgroup, 128 B apart (never shares a line with another writer)
     unsigned long long key;
@@ -48,6 +49,13 @@ struct RfOut {
 
 // ---- correspondence view -------------------------------------------------------------------------------------
 // offs[p] = first global index of part p, offs[parts] = n.  One wave computes it (lane p <-> part p).
+// (parts == 1, a plain array, needs none of this: view_count() reads the one count as a wave-uniform scalar.)
+__device__ __forceinline__ int view_count1(const pm_points_view& v)
+{
+    int c = v.cap;
+    if (v.counts) { const int raw = *v.counts; c = raw < 0 ? 0 : (raw > v.cap ? v.cap : raw); }
+    return c;
+}
 __device__ __forceinline__ void view_offsets(const pm_points_view& v, int* __restrict__ offs, int tid)
 {
     if (tid < 64) {
@@ -73,9 +81,12 @@ __device__ __forceinline__ void view_offsets(const pm_points_view& v, int* __res
 // point i of the concatenated order (i < n)
 __device__ __forceinline__ void view_point(const pm_points_view& v, const int* __restrict__ offs, int i, float2& a, float2& b)
 {
-    int p = 0;
-    while (p + 1 < v.parts && i >= offs[p + 1]) ++p;          // parts <= 64; 1 for a contiguous array
-    const size_t e = static_cast<size_t>(p) * static_cast<size_t>(v.pitch_xy) + 2 * static_cast<size_t>(i - offs[p]);
+    size_t e = 2 * static_cast<size_t>(i);
+    if (v.parts > 1) {
+        int p = 0;
+        while (p + 1 < v.parts && i >= offs[p + 1]) ++p;      // parts <= 64
+        e = static_cast<size_t>(p) * static_cast<size_t>(v.pitch_xy) + 2 * static_cast<size_t>(i - offs[p]);
+    }
     a = *reinterpret_cast<const float2*>(v.xy1 + e);
     b = *reinterpret_cast<const float2*>(v.xy2 + e);
 }
@@ -96,6 +107,94 @@ __device__ __forceinline__ bool hyp_model_view(const pm_points_view& v, const in
     return solve8(x1, y1, x2, y2, F);
 }
 
+// v_pk_fma_f32 with a coefficient broadcast out of a register PAIR by the instruction's op_sel bits (bit i of op_sel /
+// op_sel_hi picks the low or high dword of source i for the low / high result lane): d = splat(ap[A]) * b + splat(cp[C])
+// resp. + c.  hipcc knows the encoding (it emits it for a lone splat) but hoists the splats of a model into 21 v_mov
+// per hypothesis once they are used by several point slots; the asm keeps them free.  One IEEE fma per component,
+// like __builtin_elementwise_fma.
+template <int A, int C>
+__device__ __forceinline__ f32x2 pk_fma_ss(f32x2 ap, f32x2 b, f32x2 cp)
+{
+    f32x2 d;
+    if (A == 0 && C == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(d) : "v"(ap), "v"(b), "v"(cp));
+    if (A == 0 && C == 1) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,1,1]" : "=v"(d) : "v"(ap), "v"(b), "v"(cp));
+    if (A == 1 && C == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(d) : "v"(ap), "v"(b), "v"(cp));
+    if (A == 1 && C == 1) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(ap), "v"(b), "v"(cp));
+    return d;
+}
+template <int A>
+__device__ __forceinline__ f32x2 pk_fma_sv(f32x2 ap, f32x2 b, f32x2 c)
+{
+    f32x2 d;
+    if (A == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(d) : "v"(ap), "v"(b), "v"(c));
+    if (A == 1) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(ap), "v"(b), "v"(c));
+    return d;
+}
+
+// SPEC S8 on two correspondences (the packed form of inlier32, same operations bit for bit) with the model held as
+// the register pairs an LDS broadcast read delivers: p0 = (f0, f1), p1 = (f2, f3), p2 = (f4, f5), p3 = (f6, f7),
+// p4 = (f8, valid).
+template <int KIND>
+__device__ __forceinline__ void inlier_pk_model(f32x4v m0, f32x4v m1, f32x2 p4, f32x2 x, f32x2 y, f32x2 xp, f32x2 yp, float thr2,
+                                                bool& ia, bool& ib)
+{
+    const f32x2 p0 = __builtin_shufflevector(m0, m0, 0, 1), p1 = __builtin_shufflevector(m0, m0, 2, 3);
+    const f32x2 p2 = __builtin_shufflevector(m1, m1, 0, 1), p3 = __builtin_shufflevector(m1, m1, 2, 3);
+    const f32x2 a = pk_fma_sv<0>(p0, x, pk_fma_ss<1, 0>(p0, y, p1));       // f0*x + (f1*y + f2)
+    const f32x2 b = pk_fma_sv<1>(p1, x, pk_fma_ss<0, 1>(p2, y, p2));       // f3*x + (f4*y + f5)
+    const f32x2 c = pk_fma_sv<0>(p3, x, pk_fma_ss<1, 0>(p3, y, p4));       // f6*x + (f7*y + f8)
+    const f32x2 num = __builtin_elementwise_fma(xp, a, __builtin_elementwise_fma(yp, b, c));
+    const f32x2 at = pk_fma_sv<0>(p0, xp, pk_fma_ss<1, 0>(p1, yp, p3));    // f0*x' + (f3*y' + f6)
+    const f32x2 bt = pk_fma_sv<1>(p0, xp, pk_fma_ss<0, 1>(p2, yp, p3));    // f1*x' + (f4*y' + f7)
+    const f32x2 n2 = num * num;
+    const f32x2 t2 = f32x2{thr2, thr2};
+    if (KIND == PM_ERR_SAMPSON) {
+        const f32x2 den = __builtin_elementwise_fma(a, a, __builtin_elementwise_fma(b, b, __builtin_elementwise_fma(at, at, bt * bt)));
+        const f32x2 rhs = t2 * den;
+        ia = n2[0] <= rhs[0];
+        ib = n2[1] <= rhs[1];
+    } else {
+        const f32x2 r2 = t2 * __builtin_elementwise_fma(a, a, b * b);
+        const f32x2 r1 = t2 * __builtin_elementwise_fma(at, at, bt * bt);
+        ia = (n2[0] <= r2[0]) && (n2[0] <= r1[0]);
+        ib = (n2[1] <= r2[1]) && (n2[1] <= r1[1]);
+    }
+}
+
+// One tile against all `hcount` models of the workgroup, KM register slots in use (compile-time: no per-slot
+// branches).  The model of hypothesis s+1 is requested from LDS before hypothesis s is scored; the ten verdict masks
+// of a hypothesis are collected first and counted afterwards, so the scalar unit waits for the vector pipe once per
+// hypothesis, not once per v_cmp.
+template <int KIND, int PPT2, int KM>
+__device__ __forceinline__ void score_tile(const float (*__restrict__ mdl)[12], int (*__restrict__ cnt)[RF_HB_MAX], int hcount,
+                                           const f32x2 (&X)[PPT2], const f32x2 (&Y)[PPT2], const f32x2 (&XP)[PPT2],
+                                           const f32x2 (&YP)[PPT2], float thr2, bool first, int lane, int wave)
+{
+    f32x4v m0 = *reinterpret_cast<const f32x4v*>(&mdl[0][0]);
+    f32x4v m1 = *reinterpret_cast<const f32x4v*>(&mdl[0][4]);
+    f32x2 m2 = *reinterpret_cast<const f32x2*>(&mdl[0][8]);
+    for (int s = 0; s < hcount; ++s) {
+        const f32x4v c0 = m0, c1 = m1;
+        const f32x2 c2 = m2;
+        const int sn = s + 1 < hcount ? s + 1 : s;
+        m0 = *reinterpret_cast<const f32x4v*>(&mdl[sn][0]);
+        m1 = *reinterpret_cast<const f32x4v*>(&mdl[sn][4]);
+        m2 = *reinterpret_cast<const f32x2*>(&mdl[sn][8]);
+        unsigned long long va[KM], vb[KM];
+#pragma unroll
+        for (int k = 0; k < KM; ++k) {
+            bool ia, ib;
+            inlier_pk_model<KIND>(c0, c1, c2, X[k], Y[k], XP[k], YP[k], thr2, ia, ib);
+            va[k] = __ballot(ia);
+            vb[k] = __ballot(ib);
+        }
+        int c = 0;
+#pragma unroll
+        for (int k = 0; k < KM; ++k) c += __popcll(va[k]) + __popcll(vb[k]);
+        if (lane == 0) cnt[wave][s] = first ? c : cnt[wave][s] + c;
+    }
+}
+
 __device__ __forceinline__ unsigned long long wg_max_u64(unsigned long long key, unsigned long long* __restrict__ wk, int tid)
 {
     key = pm::wave_max_u64(key);
@@ -107,6 +206,21 @@ __device__ __forceinline__ unsigned long long wg_max_u64(unsigned long long key,
     for (int w = 1; w < RF_THREADS / 64; ++w) k = wk[w] > k ? wk[w] : k;
     return k;
 }
+
+// Diagnostic build only (tools/build_stamps.sh, -DPM_RF_STAMPS): shader-clock stamps of the phases, written to a
+// buffer of their own that nothing else reads (MI355X guide, "In-kernel stamps").
+#ifdef PM_RF_STAMPS
+__device__ unsigned long long g_rf_stamps[4096 * 12];
+#define RF_STAMP(i)                                                                                          \
+    do {                                                                                                     \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) {                                                         \
+            g_rf_stamps[blockIdx.x * 12 + (i)] = __builtin_amdgcn_s_memtime();                               \
+            if ((i) == 0 || (i) == 9) g_rf_stamps[blockIdx.x * 12 + 10 + ((i) ? 1 : 0)] = __builtin_amdgcn_s_memrealtime(); \
+        }                                                                                                    \
+    } while (0)
+#else
+#define RF_STAMP(i) do { } while (0)
+#endif
 
 // ---- the kernel ------------------------------------------------------------------------------------------------
 template <int KIND, int PPT2>
@@ -124,9 +238,16 @@ __global__ __launch_bounds__(RF_THREADS) void ransac_fused(pm_points_view v, uin
     __shared__ int s_wc[RF_THREADS / 64];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    view_offsets(v, s_offs, tid);
-    __syncthreads();
-    const int n = s_offs[v.parts];
+    RF_STAMP(0);
+    int n;
+    if (v.parts == 1) {
+        n = view_count1(v);
+    } else {
+        view_offsets(v, s_offs, tid);
+        __syncthreads();
+        n = s_offs[v.parts];
+    }
+    RF_STAMP(1);
 
     // ---- correspondences -> registers, one tile of RF_TILE points at a time: slot k of thread t holds points
     // base + 2*(k*256 + t) and +1 as packed pairs (x_a, x_b), (y_a, y_b), (x'_a, x'_b), (y'_a, y'_b); points >= n
@@ -145,8 +266,19 @@ __global__ __launch_bounds__(RF_THREADS) void ransac_fused(pm_points_view v, uin
             if (k < kmax) {                                      // workgroup-uniform
                 const int i0 = base + 2 * (k * RF_THREADS + tid);
                 float2 a0 = {nanv, nanv}, b0 = a0, a1 = a0, b1 = a0;
-                if (i0 < n) view_point(v, s_offs, i0, a0, b0);
-                if (i0 + 1 < n) view_point(v, s_offs, i0 + 1, a1, b1);
+                if (v.parts == 1) {
+                    // plain array: unconditional clamped loads (n >= 1 here), all of a tile's requests in flight together
+                    const int j0 = i0 < n ? i0 : n - 1, j1 = i0 + 1 < n ? i0 + 1 : n - 1;
+                    a0 = *reinterpret_cast<const float2*>(v.xy1 + 2 * static_cast<size_t>(j0));
+                    a1 = *reinterpret_cast<const float2*>(v.xy1 + 2 * static_cast<size_t>(j1));
+                    b0 = *reinterpret_cast<const float2*>(v.xy2 + 2 * static_cast<size_t>(j0));
+                    b1 = *reinterpret_cast<const float2*>(v.xy2 + 2 * static_cast<size_t>(j1));
+                    if (i0 >= n) { a0 = float2{nanv, nanv}; b0 = a0; }
+                    if (i0 + 1 >= n) { a1 = float2{nanv, nanv}; b1 = a1; }
+                } else {
+                    if (i0 < n) view_point(v, s_offs, i0, a0, b0);
+                    if (i0 + 1 < n) view_point(v, s_offs, i0 + 1, a1, b1);
+                }
                 X[k] = f32x2{a0.x, a1.x}; Y[k] = f32x2{a0.y, a1.y};
                 XP[k] = f32x2{b0.x, b1.x}; YP[k] = f32x2{b0.y, b1.y};
             }
@@ -154,10 +286,14 @@ __global__ __launch_bounds__(RF_THREADS) void ransac_fused(pm_points_view v, uin
         return kmax;
     };
     int kmax = load_tile(0);
+    RF_STAMP(2);
 
     // ---- solve: lane s solves hypothesis h0 + s (SPEC S6, S7); models stay in LDS
     const int h0 = static_cast<int>(blockIdx.x) * hb;
     const int hcount = nh - h0 < hb ? nh - h0 : hb;
+    // Lane s of the workgroup solves hypothesis s: ONE wave per 64 ids.  The solve is a ~3000-instruction fp64 stream
+    // that costs its SIMD ~24k cycles whatever the number of active lanes (measured: spreading the ids over the four
+    // waves of both co-resident workgroups doubled the phase), so ids are packed into as few waves as possible.
     if (tid < hcount) {
         double F[9];
         bool ok = false;
@@ -169,32 +305,23 @@ __global__ __launch_bounds__(RF_THREADS) void ransac_fused(pm_points_view v, uin
         s_mdl[tid][9] = ok ? 1.f : 0.f;
         s_mdl[tid][10] = 0.f; s_mdl[tid][11] = 0.f;
     }
+    RF_STAMP(3);
     __syncthreads();
+    RF_STAMP(4);
 
     // ---- score: model = LDS broadcast, lane = its own points, count = popcount of the wavefront ballot (SALU)
     for (int t = 0; t < ntiles; ++t) {
         if (t > 0) kmax = load_tile(t);
-        f32x4v m0 = *reinterpret_cast<const f32x4v*>(&s_mdl[0][0]);
-        f32x4v m1 = *reinterpret_cast<const f32x4v*>(&s_mdl[0][4]);
-        float m2 = s_mdl[0][8];
-        for (int s = 0; s < hcount; ++s) {
-            const float f[9] = {m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3], m2};
-            const int sn = s + 1 < hcount ? s + 1 : s;       // next model requested before this one is scored
-            m0 = *reinterpret_cast<const f32x4v*>(&s_mdl[sn][0]);
-            m1 = *reinterpret_cast<const f32x4v*>(&s_mdl[sn][4]);
-            m2 = s_mdl[sn][8];
-            int c = 0;
-#pragma unroll
-            for (int k = 0; k < PPT2; ++k) {
-                if (k < kmax) {
-                    bool ia, ib;
-                    inlier32_x2_flags<KIND>(f, X[k], Y[k], XP[k], YP[k], thr2, ia, ib);
-                    c += __popcll(__ballot(ia)) + __popcll(__ballot(ib));
-                }
-            }
-            if (lane == 0) s_cnt[wave][s] = t == 0 ? c : s_cnt[wave][s] + c;
+        switch (kmax) {                                      // workgroup-uniform
+#define PM_CASE(KM_) case KM_: score_tile<KIND, PPT2, (KM_ <= PPT2 ? KM_ : PPT2)>(s_mdl, s_cnt, hcount, X, Y, XP, YP, thr2, t == 0, lane, wave); break;
+            PM_CASE(1) PM_CASE(2) PM_CASE(3) PM_CASE(4) PM_CASE(5)
+#undef PM_CASE
+            default:
+                for (int s = lane; s < hcount; s += 64) s_cnt[wave][s] = t == 0 ? 0 : s_cnt[wave][s];   // empty tile (n == 0)
+                break;
         }
     }
+    RF_STAMP(5);
     __syncthreads();
 
     // ---- the workgroup's best key (SPEC S9: most inliers, then lowest id) and its slot
@@ -219,23 +346,38 @@ __global__ __launch_bounds__(RF_THREADS) void ransac_fused(pm_points_view v, uin
         }
     }
     __syncthreads();
-    if (s_role == 0) return;
+    RF_STAMP(6);
+    if (s_role == 0) { RF_STAMP(9); return; }
 
     // ---- last workgroup: every slot is complete.  Winner = max key over the slots.
     if (tid == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    // every thread requests key AND model of its slots at once (one memory round trip), then the owner of the
+    // winning key hands its model over through LDS
     unsigned long long kb = 0ull;
+    double fb[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) fb[i] = 0.0;
     for (int j = tid; j < static_cast<int>(gridDim.x); j += RF_THREADS) {
         const unsigned long long kj = __hip_atomic_load(&slots[j].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        kb = kj > kb ? kj : kb;
+        double fj[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) fj[i] = __hip_atomic_load(&slots[j].F[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (kj > kb) {
+            kb = kj;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) fb[i] = fj[i];
+        }
     }
     const unsigned long long kwin = wg_max_u64(kb, s_wk, tid);
     const bool ok = kwin != 0ull && n >= 8;
-    if (tid < 9) {
-        const int owner = ok ? static_cast<int>((static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(kwin)) - hyp_begin) / hb) : 0;
-        const double fv = __hip_atomic_load(&slots[owner].F[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_F64[tid] = ok ? fv : 0.0;
+    if (tid < 9) s_F64[tid] = 0.0;
+    __syncthreads();
+    if (ok && kb == kwin) {                                  // exactly one thread: keys of distinct ids differ
+#pragma unroll
+        for (int i = 0; i < 9; ++i) s_F64[i] = fb[i];
     }
     __syncthreads();
+    RF_STAMP(7);
     if (out.shard) {
         if (tid < 9) out.rec->F[tid] = s_F64[tid];
         if (tid == 9) out.rec->key = ok ? kwin : 0ull;
@@ -279,6 +421,8 @@ __global__ __launch_bounds__(RF_THREADS) void ransac_fused(pm_points_view v, uin
         if (out.n_inliers) *out.n_inliers = tot;
         if (out.fo) out.fo->n_inliers = tot;
     }
+    RF_STAMP(8);
+    RF_STAMP(9);
 }
 
 // ---- finish of a sharded run: winner among the gathered records, its mask over the viewed correspondences -------
@@ -295,11 +439,11 @@ __global__ __launch_bounds__(RF_THREADS) void ransac_finish(pm_points_view v, co
     __shared__ int s_wc[RF_THREADS / 64];
     __shared__ int s_last;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    view_offsets(v, s_offs, tid);
+    if (v.parts > 1) view_offsets(v, s_offs, tid);
     unsigned long long kb = 0ull;
     for (int j = tid; j < nrec; j += RF_THREADS) { const unsigned long long kj = recs[j].key; kb = kj > kb ? kj : kb; }
     const unsigned long long kwin = wg_max_u64(kb, s_wk, tid);          // (its barriers also publish s_offs)
-    const int n = s_offs[v.parts];
+    const int n = v.parts > 1 ? s_offs[v.parts] : view_count1(v);
     const bool ok = kwin != 0ull && n >= 8;
     int owner = 0;
     for (int j = 0; j < nrec; ++j) owner = recs[j].key == kwin ? j : owner;   // keys of distinct ids differ
@@ -364,12 +508,14 @@ int sync_words(pm_ctx* ctx, int** out)
 
 }  // namespace
 
-// Hypothesis ids per workgroup: whole rounds of one workgroup per CU, at most RF_HB_MAX ids each.
+// Hypothesis ids per workgroup: whole rounds of TWO workgroups per CU (a lone wave issues a VALU instruction every
+// 4-8 cycles; two waves per SIMD fill the vector pipe: score phase 19 -> 8 us at C3), at most RF_HB_MAX ids each.
 int fused_hb(const pm_ctx* ctx, long long nh)
 {
-    const long long per_round = static_cast<long long>(ctx->n_cu) * RF_HB_MAX;
+    const long long wgs = 2LL * ctx->n_cu;
+    const long long per_round = wgs * RF_HB_MAX;
     const long long rounds = (nh + per_round - 1) / per_round;
-    long long hb = (nh + ctx->n_cu * rounds - 1) / (ctx->n_cu * rounds);
+    long long hb = (nh + wgs * rounds - 1) / (wgs * rounds);
     if (hb < 1) hb = 1;
     if (hb > RF_HB_MAX) hb = RF_HB_MAX;
     return static_cast<int>(hb);
@@ -422,6 +568,14 @@ int fused_launch(pm_ctx* ctx, const pm_points_view& v, const pm_ransac_params* p
 }  // namespace pm_ransac
 
 using namespace pm_ransac;
+
+#ifdef PM_RF_STAMPS
+extern "C" int pm_debug_rf_stamps(unsigned long long* out, int n_words)
+{
+    PM_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rf_stamps), sizeof(unsigned long long) * n_words, 0, hipMemcpyDeviceToHost));
+    return PM_OK;
+}
+#endif
 
 extern "C" int pm_ransac_shard_parts_dev(pm_ctx* ctx, const pm_points_view* view, const pm_ransac_params* p,
                                          pm_ransac_record* d_record)

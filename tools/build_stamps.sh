@@ -1,0 +1,13 @@
+#!/bin/bash
+# Diagnostic build of the one-launch RANSAC kernel with in-kernel phase stamps (-DPM_RF_STAMPS); never shipped.
+# Output: points_matching_amd/build/abl/libpm_rfstamps.so; use with PM_LIB_PATH=... python tools/prof_ransac_stamps.py
+set -e
+cd "$(dirname "$0")/.."
+python -m points_matching_amd.build > /dev/null
+B=points_matching_amd/build
+mkdir -p $B/abl
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Iinclude -Ipoints_matching_amd/csrc"
+/opt/rocm/bin/hipcc $F -DPM_RF_STAMPS -x hip -c points_matching_amd/csrc/ransac_fused.hip -o /tmp/rf_stamps.o
+objs=$(ls $B/*.o | grep -v ransac_fused.o)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $B/abl/libpm_rfstamps.so /tmp/rf_stamps.o $objs
+echo built $B/abl/libpm_rfstamps.so
