@@ -106,6 +106,8 @@ int  pm_version(void);                 /* major*100 + minor */
  *          (decided on the device, no host round trip: both coarse kernels are enqueued and the one
  *          that does not apply exits at once) and the f32-MFMA route otherwise.  Anything else:
  *          exact VALU kernel.  All routes produce bit-identical output (tests assert it). */
+/* Device pointers of the _dev form: rows are read as 16-byte vectors when dim % 4 == 0 and both base pointers are
+ * 16-byte aligned (hipMalloc / torch allocations are); otherwise the call takes the exact scalar-load kernel. */
 #define PM_MAX_K 16
 #define PM_KNN_FORCE_EXACT  1   /* exact VALU kernel only                                           */
 #define PM_KNN_FORCE_F32    2   /* f32-MFMA coarse route only (any finite floats)                   */
@@ -334,6 +336,31 @@ int pm_batch_run(pm_batch* b, const pm_pair_job* jobs, int n_jobs, float ratio, 
 /* Page-lock / release a caller-owned host buffer (hipHostRegister) so the batch copies overlap. */
 int pm_host_register(void* ptr, size_t bytes);
 int pm_host_unregister(void* ptr);
+
+/* ---- the path over the GPUs of one node (SURVEY.md 8b `pm_ransac_reduce`, 8e) ----------------------------
+ * One host thread, one context per device, one RCCL communicator set (ncclCommInitAll over xGMI); RCCL is bound
+ * at run time, so single-GPU users never load it.  `devices`: HIP ordinals (NULL: 0 .. n_dev-1).
+ *   pm_mgpu_ransac_fundamental  main.cpp:95-98 with the hypothesis ids cut into n_dev contiguous ranges over
+ *       replicated correspondences; the exchange is ONE all-gather of the 80-byte pm_ransac_record per device
+ *       (arg-max all-reduce with its payload); every device finishes from the winning record, device 0's answer
+ *       is returned.  Same bits as pm_ransac_fundamental for any n_dev (tests assert it).
+ *   pm_mgpu_match_ransac        main.cpp:46 -> :49-69 (ratio form) -> :89-91 -> :95-98 (BASELINE config C4): query
+ *       rows cut into n_dev contiguous blocks (train set replicated), all-gather #1 of the survivor blocks, RANSAC
+ *       as above over the gathered view, all-gather #2 of the records.  desc1/desc2: n x dim float32 rows
+ *       (binary == 0, L2, knn_flags as pm_bf_knn_l2_f32) or n x dim bytes (binary != 0, Hamming).  Outputs: `good`
+ *       (n1 records, first *n_good valid, query order, queryIdx = row of desc1), F, mask (per good match), counts.
+ *       PM_E_TOO_FEW / PM_E_NO_MODEL as pm_ransac_fundamental (good / *n_good are valid either way). */
+typedef struct pm_mgpu pm_mgpu;   /* opaque */
+int pm_mgpu_create(int n_dev, const int* devices, pm_mgpu** out);
+int pm_mgpu_destroy(pm_mgpu* mg);
+int pm_mgpu_size(const pm_mgpu* mg);
+pm_ctx* pm_mgpu_ctx(pm_mgpu* mg, int i);        /* device i's context (options, timing); owned by mg */
+int pm_mgpu_ransac_fundamental(pm_mgpu* mg, const float* xy1, const float* xy2, int n, const pm_ransac_params* p,
+                               double F[9], uint8_t* mask, int* n_inliers, uint64_t* best_key);
+int pm_mgpu_match_ransac(pm_mgpu* mg, const void* desc1, int n1, const void* desc2, int n2, int dim, int binary,
+                         const float* kp1_xy, const float* kp2_xy, float ratio, int knn_flags,
+                         const pm_ransac_params* p, pm_match* good, int* n_good, double F[9], uint8_t* mask,
+                         int* n_inliers, uint64_t* best_key);
 
 /* ---- residual report (main.cpp:103-123) -----------------------------------------------------
  * r[i] = [xa ya 1] * F * [xb yb 1]^T in fp64.  transposed != 0 reproduces the reference

@@ -36,6 +36,7 @@ EXPORTS = [
     "pm_ransac_fundamental", "pm_ransac_score_dev", "pm_ransac_score_devn", "pm_ransac_model_from_hyp",
     "pm_ransac_model_from_key_dev", "pm_ransac_run_dev", "pm_ransac_shard_parts_dev", "pm_ransac_finish_parts_dev",
     "pm_ctx_set_option", "pm_ctx_get_option",
+    "pm_mgpu_create", "pm_mgpu_destroy", "pm_mgpu_size", "pm_mgpu_ctx", "pm_mgpu_ransac_fundamental", "pm_mgpu_match_ransac",
     "pm_batch_create", "pm_batch_destroy", "pm_batch_run", "pm_host_register", "pm_host_unregister",
     "pm_lmeds_fundamental", "pm_lmeds_fundamental_dev", "pm_lmeds_default_iters", "pm_ransac7_adaptive",
     "pm_epipolar_residuals", "pm_f_scale_f33", "pm_epilines", "pm_epiline_endpoints",
@@ -471,3 +472,60 @@ def host_register(arr):
 
 def host_unregister(arr):
     _check(lib().pm_host_unregister(C.c_void_p(arr.ctypes.data)))
+
+
+# ---- the path over the GPUs of one node (single process, RCCL behind the C ABI) ----------------------
+
+class MultiGpu:
+    """pm_mgpu wrapper."""
+
+    def __init__(self, n_dev, devices=None):
+        self._h = C.c_void_p()
+        arr = (C.c_int * n_dev)(*devices) if devices is not None else None
+        _check(lib().pm_mgpu_create(n_dev, arr, C.byref(self._h)))
+        self.n = n_dev
+
+    def close(self):
+        if self._h:
+            lib().pm_mgpu_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def ransac_fundamental(self, xy1, xy2, iters, thresh_px, seed, kind=PM_ERR_SAMPSON, hyp_begin=0):
+        xy1 = np.ascontiguousarray(xy1, np.float32).reshape(-1, 2)
+        xy2 = np.ascontiguousarray(xy2, np.float32).reshape(-1, 2)
+        n = xy1.shape[0]
+        prm = RansacParams(hyp_begin, iters, seed, thresh_px, kind)
+        F = np.zeros(9, np.float64)
+        mask = np.zeros(max(n, 1), np.uint8)
+        ninl, key = C.c_int(), C.c_uint64()
+        rc = lib().pm_mgpu_ransac_fundamental(self._h, _p(xy1), _p(xy2), n, C.byref(prm), _p(F), _p(mask), C.byref(ninl),
+                                              C.byref(key))
+        if rc not in (PM_OK, PM_E_NO_MODEL, PM_E_TOO_FEW):
+            _check(rc)
+        return rc, F.reshape(3, 3), mask[:n], ninl.value, key.value
+
+    def match_ransac(self, desc1, desc2, kp1, kp2, ratio, iters, thresh_px, seed, knn_flags=0, kind=PM_ERR_SAMPSON):
+        """Returns (status, good, F(3x3), mask, n_inliers, best_key)."""
+        binary = desc1.dtype == np.uint8
+        desc1 = np.ascontiguousarray(desc1, np.uint8 if binary else np.float32)
+        desc2 = np.ascontiguousarray(desc2, desc1.dtype)
+        kp1 = np.ascontiguousarray(kp1, np.float32).reshape(-1, 2)
+        kp2 = np.ascontiguousarray(kp2, np.float32).reshape(-1, 2)
+        n1, dim = desc1.shape
+        prm = RansacParams(0, iters, seed, thresh_px, kind)
+        good = np.zeros(n1, MATCH_DTYPE)
+        F = np.zeros(9, np.float64)
+        mask = np.zeros(n1, np.uint8)
+        ngood, ninl, key = C.c_int(), C.c_int(), C.c_uint64()
+        rc = lib().pm_mgpu_match_ransac(self._h, _p(desc1), n1, _p(desc2), desc2.shape[0], dim, int(binary), _p(kp1), _p(kp2),
+                                        C.c_float(ratio), knn_flags, C.byref(prm), _p(good), C.byref(ngood), _p(F), _p(mask),
+                                        C.byref(ninl), C.byref(key))
+        if rc not in (PM_OK, PM_E_NO_MODEL, PM_E_TOO_FEW):
+            _check(rc)
+        return rc, good[:ngood.value].copy(), F.reshape(3, 3), mask[:ngood.value].copy(), ninl.value, key.value

@@ -342,6 +342,9 @@ __global__ __launch_bounds__(256) void knn_hamming_refine(const uint32_t* __rest
             }
         }
     }
+    // the list entries were written by other lanes of this wave: LDS stores before the loads, explicitly
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     // candidate groups: 8 rows each, one row per lane, 8 groups per round
     for (int base = 0; base < 8 * total; base += 64) {
         const int t = base + lane;

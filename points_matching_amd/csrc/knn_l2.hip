@@ -436,6 +436,10 @@ __global__ __launch_bounds__(256) void knn_l2_refine(
                 }
             }
         }
+        // the candidate list was written by some lanes and is read by others of the SAME wave: order the LDS
+        // stores before the loads explicitly (no workgroup barrier: waves run on independent queries)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         const int nc = 4 * total;                           // every candidate group is 4 consecutive rows
         for (int r0 = 0; r0 < nc; r0 += 8) {                // 8 rows per round, 8 lanes each
             const int rank = r0 + grp;
@@ -526,7 +530,7 @@ __global__ __launch_bounds__(256) void knn_l2_exact(const float* __restrict__ Q,
     const int full8 = dim / 8 * 8;              // columns covered by the 8-lane accumulators
     const int ntiles = (nt + TILE_T - 1) / TILE_T;
     const int nchunks = (dim + EX_KC - 1) / EX_KC;
-    const bool vec4 = (dim & 3) == 0;
+    const bool vec4 = (dim & 3) == 0 && ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(T)) & 15) == 0;
 
     uint64_t floor_key[EX_QPW];                 // keys <= floor were emitted by earlier passes
     bool have_floor = false;
@@ -693,7 +697,10 @@ extern "C" int pm_bf_knn_l2_f32_dev(pm_ctx* ctx, const float* dq, int nq, const 
     if (nq == 0) return PM_OK;
     PM_HIP_CHECK(hipSetDevice(ctx->device));
 
-    const bool fast = !(flags & PM_KNN_FORCE_EXACT) && k <= 2 && (dim % 4) == 0 && dim <= 128 && nt >= 1;
+    // the MFMA routes read rows as 16-byte vectors: dim % 4 == 0 AND 16-byte aligned base pointers (anything else
+    // takes the exact kernel, whose loads are scalar unless both hold)
+    const bool aligned16 = ((reinterpret_cast<uintptr_t>(dq) | reinterpret_cast<uintptr_t>(dt)) & 15) == 0;
+    const bool fast = !(flags & PM_KNN_FORCE_EXACT) && k <= 2 && (dim % 4) == 0 && dim <= 128 && nt >= 1 && aligned16;
     if (!fast) return run_exact(ctx, dq, nq, dt, nt, dim, k, dout);
     const int route = (flags & PM_KNN_FORCE_F32) ? ROUTE_F32 : (flags & PM_KNN_HINT_INTEGER) ? ROUTE_F16_HINT : ROUTE_AUTO;
     const bool want32 = route != ROUTE_F16_HINT, want16 = route != ROUTE_F32;

@@ -143,6 +143,16 @@ extern "C" int pm_batch_run(pm_batch* b, const pm_pair_job* jobs, int n_jobs, fl
     }
     PM_HIP_CHECK(hipSetDevice(b->device));
     int rc = PM_OK;
+    // A failing HIP call must not leave the loop by `return`: copies may still be in flight on the caller's buffers
+    // and a lane would keep a stale `pending` job for the next call.  Every failure falls through to the drain below.
+#define PM_BATCH_HIP(expr)                                                                     \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess && rc == PM_OK) {                                                 \
+            pm::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            rc = PM_E_HIP;                                                                     \
+        }                                                                                      \
+    } while (0)
     for (int j = 0; j < n_jobs && rc == PM_OK; ++j) {
         Lane& L = b->lanes[j % b->n_lanes];
         rc = lane_collect(b, L, results, good, masks);
@@ -150,11 +160,11 @@ extern "C" int pm_batch_run(pm_batch* b, const pm_pair_job* jobs, int n_jobs, fl
         const pm_pair_job& jb = jobs[j];
         hipStream_t s = L.ctx->stream;
         const size_t n1 = static_cast<size_t>(jb.n1), n2 = static_cast<size_t>(jb.n2);
-        PM_HIP_CHECK(hipMemcpyAsync(L.dq, jb.desc1, sizeof(float) * n1 * b->dim, hipMemcpyHostToDevice, s));
-        PM_HIP_CHECK(hipMemcpyAsync(L.dt, jb.desc2, sizeof(float) * n2 * b->dim, hipMemcpyHostToDevice, s));
-        PM_HIP_CHECK(hipMemcpyAsync(L.dkp1, jb.kp1_xy, sizeof(float) * 2 * n1, hipMemcpyHostToDevice, s));
-        PM_HIP_CHECK(hipMemcpyAsync(L.dkp2, jb.kp2_xy, sizeof(float) * 2 * n2, hipMemcpyHostToDevice, s));
-        rc = pm_bf_knn_l2_f32_dev(L.ctx, L.dq, jb.n1, L.dt, jb.n2, b->dim, 2, knn_flags, L.dknn);
+        PM_BATCH_HIP(hipMemcpyAsync(L.dq, jb.desc1, sizeof(float) * n1 * b->dim, hipMemcpyHostToDevice, s));
+        PM_BATCH_HIP(hipMemcpyAsync(L.dt, jb.desc2, sizeof(float) * n2 * b->dim, hipMemcpyHostToDevice, s));
+        PM_BATCH_HIP(hipMemcpyAsync(L.dkp1, jb.kp1_xy, sizeof(float) * 2 * n1, hipMemcpyHostToDevice, s));
+        PM_BATCH_HIP(hipMemcpyAsync(L.dkp2, jb.kp2_xy, sizeof(float) * 2 * n2, hipMemcpyHostToDevice, s));
+        if (rc == PM_OK) rc = pm_bf_knn_l2_f32_dev(L.ctx, L.dq, jb.n1, L.dt, jb.n2, b->dim, 2, knn_flags, L.dknn);
         if (rc == PM_OK)
             rc = pm_filter_ratio_gather_dev(L.ctx, L.dknn, jb.n1, 2, ratio, L.dkp1, L.dkp2, L.dgood, L.dxy1, L.dxy2,
                                             &L.dres->n_good);
@@ -162,13 +172,15 @@ extern "C" int pm_batch_run(pm_batch* b, const pm_pair_job* jobs, int n_jobs, fl
             rc = pm_ransac_run_dev(L.ctx, L.dxy1, L.dxy2, jb.n1, &L.dres->n_good, p, &L.dres->key, L.dres->F, L.dmask,
                                    &L.dres->n_inliers);
         if (rc != PM_OK) break;
-        PM_HIP_CHECK(hipMemcpyAsync(L.hres, L.dres, sizeof(DevResult), hipMemcpyDeviceToHost, s));
-        if (good) PM_HIP_CHECK(hipMemcpyAsync(L.hgood, L.dgood, sizeof(pm_match) * n1, hipMemcpyDeviceToHost, s));
-        if (masks) PM_HIP_CHECK(hipMemcpyAsync(L.hmask, L.dmask, n1, hipMemcpyDeviceToHost, s));
-        PM_HIP_CHECK(hipEventRecord(L.done, s));
+        PM_BATCH_HIP(hipMemcpyAsync(L.hres, L.dres, sizeof(DevResult), hipMemcpyDeviceToHost, s));
+        if (good) PM_BATCH_HIP(hipMemcpyAsync(L.hgood, L.dgood, sizeof(pm_match) * n1, hipMemcpyDeviceToHost, s));
+        if (masks) PM_BATCH_HIP(hipMemcpyAsync(L.hmask, L.dmask, n1, hipMemcpyDeviceToHost, s));
+        PM_BATCH_HIP(hipEventRecord(L.done, s));
+        if (rc != PM_OK) break;
         L.pending = j;
         L.pending_n1 = jb.n1;
     }
+#undef PM_BATCH_HIP
     // drain in job order (also after an error: nothing may stay in flight on the caller's buffers)
     for (int i = 0; i < b->n_lanes; ++i) {
         if (rc == PM_OK) rc = lane_collect(b, b->lanes[i], results, good, masks);

@@ -27,7 +27,7 @@ def test_cli_stdout_matches_reference_format(tmp_path, oracle, mode):
         paths[name] = str(tmp_path / (name + ".pmm"))
         io.save_pmm(paths[name], w[name])
     cmd = [exe, "--desc1", paths["q"], "--desc2", paths["t"], "--kp1", paths["kp1"], "--kp2", paths["kp2"],
-           "--filter", mode, "--iters", "400", "--thresh", "1.0", "--seed", "99", "--json"]
+           "--filter", mode, "--method", "ransac8", "--iters", "400", "--thresh", "1.0", "--seed", "99", "--json"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     lines = out.stdout.splitlines()
@@ -74,3 +74,56 @@ def test_cli_7point_lmeds_method(tmp_path, oracle):
     rc, F, mask, ninl, best, med = oracle.lmeds_fundamental(xy1, xy2, 300, 5, nthreads=4)
     assert rc == 0 and js["matches"] == good.size and js["inliers"] == ninl and js["best_hyp"] == best
     assert np.array_equal(np.array(js["F"]), oracle.f_scale_f33(F).reshape(9))
+
+
+def _write_inputs(tmp_path, w):
+    paths = {}
+    for name in ("q", "t", "kp1", "kp2"):
+        paths[name] = str(tmp_path / (name + ".pmm"))
+        io.save_pmm(paths[name], w[name])
+    return [build.HOST_BIN, "--desc1", paths["q"], "--desc2", paths["t"], "--kp1", paths["kp1"], "--kp2", paths["kp2"]]
+
+
+def test_cli_epilines_print_and_overlay(tmp_path, oracle):
+    """main.cpp:127-142: computeCorrespondEpilines(selPoints1, 1, F) and the cv::line end points, printed and drawn."""
+    w = synth.pair_workload(nq=260, nt=240, dim=128, seed=12, planted=0.5, kind="sift")
+    ppm = str(tmp_path / "epi.ppm")
+    cmd = _write_inputs(tmp_path, w) + ["--filter", "ratio", "--method", "ransac8", "--iters", "300", "--seed", "3", "--quiet",
+                                        "--print-epilines", "--epilines", ppm, "--canvas", "993", "660"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    good = oracle.filter_ratio(oracle.bf_knn_l2(w["q"], w["t"], 2), 0.8)
+    xy1 = oracle.gather_points(w["kp1"], good["queryIdx"])
+    xy2 = oracle.gather_points(w["kp2"], good["trainIdx"])
+    rc, F, _, _, _ = oracle.ransac_fundamental(xy1, xy2, 300, 1.0, 3)
+    F = oracle.f_scale_f33(F)
+    lines = oracle.epilines(xy1, 1, F)
+    ends = oracle.epiline_endpoints(lines, 993)
+    exp = ["epiline = %d %s %s %s  (%d, %d) -> (%d, %d)" % (i, _g(lines[i, 0]), _g(lines[i, 1]), _g(lines[i, 2]),
+                                                             ends[i, 0], ends[i, 1], ends[i, 2], ends[i, 3])
+           for i in range(good.size)]
+    assert out.stdout.splitlines() == exp
+    raw = open(ppm, "rb").read()
+    assert raw.startswith(b"P6\n993 660\n255\n")
+    px = np.frombuffer(raw[len(b"P6\n993 660\n255\n"):], np.uint8).reshape(660, 993, 3)
+    white = (px == 255).all(axis=2)
+    assert white.sum() > 993                      # at least one full-width line was drawn
+    # a drawn line passes through the pixel its own equation gives at mid-width
+    i = next(k for k in range(good.size) if 0 <= ends[k, 1] < 660 and 0 <= ends[k, 3] < 660)
+    ymid = int(round(-(lines[i, 2] + lines[i, 0] * 496) / lines[i, 1]))
+    assert white[max(0, ymid - 1):ymid + 2, 496].any()
+
+
+def test_cli_mgpu_path_equals_single_device_path(tmp_path):
+    """--gpus N runs through pm_mgpu_match_ransac (RCCL behind the C ABI); with one device it must print exactly
+    what the single-context path prints."""
+    w = synth.pair_workload(nq=700, nt=650, dim=128, seed=5, planted=0.5, kind="sift")
+    base = _write_inputs(tmp_path, w) + ["--filter", "ratio", "--method", "ransac8", "--iters", "500", "--seed", "11", "--json"]
+    a = subprocess.run(base, capture_output=True, text=True, timeout=120)
+    b = subprocess.run(base + ["--gpus", "1", "--mgpu"], capture_output=True, text=True, timeout=180)
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr, b.stderr)
+    la, lb = a.stdout.splitlines(), b.stdout.splitlines()
+    assert la[:-1] == lb[:-1]
+    ja, jb = json.loads(la[-1]), json.loads(lb[-1])
+    for k in ("matches", "inliers", "best_hyp", "F", "mean_abs_x1Fx2"):
+        assert ja[k] == jb[k], k
