@@ -15,6 +15,7 @@
 // PyTorch-ROCm, else /opt/rocm's), so single-GPU users of libpm_hip.so never load it.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <unistd.h>
 
 #include <new>
 #include <vector>
@@ -132,7 +133,14 @@ extern "C" int pm_mgpu_create(int n_dev, const int* devices, pm_mgpu** out)
         if (rc != PM_OK) { (void)pm_mgpu_destroy(mg); return rc; }
     }
     std::vector<ncclComm_t> comms(n_dev, nullptr);
+    // RCCL prints a version banner on fd 1 when its first communicator is made; the drop-in's stdout is the
+    // reference's surface (main.cpp:58-59, :73-76, :119, :123), so fd 1 points at stderr for the duration of the call.
+    fflush(stdout);
+    const int saved_out = dup(1);
+    if (saved_out >= 0) (void)dup2(2, 1);
     ncclResult_t r = g_rccl.CommInitAll(comms.data(), n_dev, list.data());
+    fflush(stdout);
+    if (saved_out >= 0) { (void)dup2(saved_out, 1); (void)close(saved_out); }
     if (r != ncclSuccess) {
         pm::set_error("ncclCommInitAll failed: %s", g_rccl.GetErrorString(r));
         (void)pm_mgpu_destroy(mg);
