@@ -1,0 +1,130 @@
+"""Independent correctness evidence for the parts of the path whose OpenCV arithmetic cannot be pinned (SURVEY.md 8c:
+"parity unpinned"): the oracle and the kernels share one specification, so bit-equality between them proves a
+consistent transcription, not correctness.  Here the oracle is checked against DIFFERENT algorithms:
+  * the 8-point solver (docs/SPEC.md S7: Householder QR null vector + one-sided Jacobi rank-2) against numpy's
+    SVD-based normalised 8-point (Hartley) on 1500 random minimal samples;
+  * the division-free fp32 Sampson / symmetric-epipolar predicates (S8) against a float64 evaluation of the textbook
+    formulas, away from the threshold;
+  * the canonical fp32 squared distance (S1) against math.fsum within its a-priori error bound;
+  * the sampler (S6) for uniformity.
+GPU twins of the first two live in tests/test_independent_gpu.py."""
+import math
+
+import numpy as np
+import pytest
+
+
+def np_eight_point(p1, p2):
+    """Textbook normalised 8-point with numpy's LAPACK SVD.  p1, p2: 8 x 2 float64.  x2^T F x1 = 0."""
+    def hartley(p):
+        c = p.mean(axis=0)
+        md = np.sqrt(((p - c) ** 2).sum(axis=1)).mean()
+        s = math.sqrt(2.0) / md
+        T = np.array([[s, 0, -s * c[0]], [0, s, -s * c[1]], [0, 0, 1.0]])
+        return (p - c) * s, T
+    a, T1 = hartley(p1)
+    b, T2 = hartley(p2)
+    A = np.stack([b[:, 0] * a[:, 0], b[:, 0] * a[:, 1], b[:, 0], b[:, 1] * a[:, 0], b[:, 1] * a[:, 1], b[:, 1],
+                  a[:, 0], a[:, 1], np.ones(8)], axis=1)
+    _, sv, Vt = np.linalg.svd(A)                     # 8 x 9: the null vector is the last row of Vt
+    Fn = Vt[-1].reshape(3, 3)
+    U, S, Wt = np.linalg.svd(Fn)
+    Fn = U @ np.diag([S[0], S[1], 0.0]) @ Wt
+    F = T2.T @ Fn @ T1
+    F /= np.linalg.norm(F)
+    if F[2, 2] < 0:
+        F = -F
+    return F, sv, S
+
+
+def test_solver_agrees_with_numpy_svd_eight_point(oracle):
+    rng = np.random.default_rng(2024)
+    worst, checked = 0.0, 0
+    for trial in range(1500):
+        # a real two-view geometry (random camera pair, points in front of both) plus pixel noise
+        X = np.column_stack([rng.uniform(-3, 3, 8), rng.uniform(-2, 2, 8), rng.uniform(4, 12, 8)])
+        ang = rng.normal(0, 0.08, 3)
+        Rx = np.array([[1, 0, 0], [0, math.cos(ang[0]), -math.sin(ang[0])], [0, math.sin(ang[0]), math.cos(ang[0])]])
+        Ry = np.array([[math.cos(ang[1]), 0, math.sin(ang[1])], [0, 1, 0], [-math.sin(ang[1]), 0, math.cos(ang[1])]])
+        Rz = np.array([[math.cos(ang[2]), -math.sin(ang[2]), 0], [math.sin(ang[2]), math.cos(ang[2]), 0], [0, 0, 1]])
+        R, t = Rz @ Ry @ Rx, np.array([1.0, rng.normal(0, 0.1), rng.normal(0, 0.1)])
+        K = np.array([[1000.0, 0, 496.5], [0, 1000.0, 330.0], [0, 0, 1]])
+        x1 = (K @ X.T).T
+        x2 = (K @ (R @ X.T + t[:, None])).T
+        p1 = (x1[:, :2] / x1[:, 2:]).astype(np.float32).astype(np.float64) + rng.normal(0, 0.5, (8, 2))
+        p2 = (x2[:, :2] / x2[:, 2:]).astype(np.float32).astype(np.float64) + rng.normal(0, 0.5, (8, 2))
+        ok, F = oracle.solve8(p1, p2)
+        F_np, sv, S = np_eight_point(p1, p2)
+        assert ok
+        # conditioning of this sample: the null vector is determined up to ~eps / (relative gap of A's 8th singular
+        # value), the rank-2 projection up to ~eps / (relative gap between F's 2nd and 3rd singular values)
+        gap = min(sv[7] / sv[0], (S[1] - S[2]) / S[0])
+        if gap < 1e-5:
+            continue                                  # nearly degenerate sample: the two algorithms may legitimately differ
+        err = min(np.linalg.norm(F - F_np), np.linalg.norm(F + F_np))
+        assert err <= 5e-13 / gap + 1e-13, (trial, err, gap)
+        worst = max(worst, err)
+        checked += 1
+        assert abs(np.linalg.norm(F) - 1) < 1e-14 and F[2, 2] >= 0
+        assert abs(np.linalg.det(F)) < 1e-12          # rank 2
+    assert checked >= 1300
+    assert worst < 1e-9
+
+
+def _sampson64(F, x1, x2):
+    x1h = np.column_stack([x1, np.ones(len(x1))]).astype(np.float64)
+    x2h = np.column_stack([x2, np.ones(len(x2))]).astype(np.float64)
+    Fx = x1h @ F.T                                   # rows: F x1
+    Ftx = x2h @ F                                    # rows: F^T x2
+    num = (x2h * Fx).sum(axis=1)
+    samp = num ** 2 / (Fx[:, 0] ** 2 + Fx[:, 1] ** 2 + Ftx[:, 0] ** 2 + Ftx[:, 1] ** 2)
+    d2 = num ** 2 / (Fx[:, 0] ** 2 + Fx[:, 1] ** 2)   # squared distance of x2 to the line F x1
+    d1 = num ** 2 / (Ftx[:, 0] ** 2 + Ftx[:, 1] ** 2)
+    return samp, np.maximum(d1, d2)
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_inlier_predicates_agree_with_float64_formulas(oracle, kind):
+    from points_matching_amd import synth
+    total = 0
+    for seed in range(6):
+        x1, x2, Fgt, _ = synth.two_view(3000, seed=seed, outlier_frac=0.5, noise_px=1.0)
+        ok, F, F32 = oracle.hyp_model(x1, x2, 77, seed)     # some hypothesis of this pair
+        if not ok:
+            continue
+        for thr in (0.5, 1.0, 3.0):
+            cnt, mask = oracle.score(F32, x1, x2, thr, kind)
+            samp, sym = _sampson64(F32.astype(np.float64), x1, x2)
+            e = samp if kind == 0 else sym
+            far = np.abs(e / thr ** 2 - 1.0) > 1e-3          # fp32 evaluation vs fp64: decisive only away from tau^2
+            assert far.sum() > 0.98 * far.size
+            assert ((e <= thr ** 2)[far] == mask.astype(bool)[far]).all()
+            assert cnt == int(mask.sum())
+            total += int(far.sum())
+    assert total > 20000
+
+
+def test_canonical_distance_within_its_bound_of_the_exact_sum(oracle):
+    rng = np.random.default_rng(5)
+    for dim in (1, 7, 8, 31, 64, 128, 200):
+        for _ in range(200):
+            a = rng.normal(0, 1, dim).astype(np.float32)
+            b = rng.normal(0, 1, dim).astype(np.float32)
+            exact = math.fsum((float(x) - float(y)) ** 2 for x, y in zip(a, b))
+            got = float(oracle.l2sqr(a, b))
+            # each term: one rounding of the difference (2 eps relative in the square) + one of the product; the sum:
+            # at most ceil(dim/8) + 4 additions on any path.  gamma = that many half-ulps of 2^-24, bounded generously.
+            gamma = (math.ceil(dim / 8) + 8) * 2.0 ** -24 * 1.01
+            assert abs(got - exact) <= gamma * exact + 1e-45, (dim, got, exact)
+
+
+def test_sampler_is_uniform_and_distinct(oracle):
+    n = 97
+    counts = np.zeros(n, np.int64)
+    for h in range(20000):
+        idx = oracle.sample8(0xABCDEF, h, n)
+        assert len(set(idx.tolist())) == 8 and idx.min() >= 0 and idx.max() < n
+        counts[idx] += 1
+    exp = 20000 * 8 / n
+    chi2 = ((counts - exp) ** 2 / exp).sum()
+    assert chi2 < 170                                # 96 degrees of freedom: P(chi2 > 170) ~ 5e-6

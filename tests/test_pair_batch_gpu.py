@@ -75,3 +75,28 @@ def test_batch_pinned_inputs_and_argument_checks():
     b.close()
     for a in bufs:
         pm.api.host_unregister(a)
+
+
+def test_batch_at_config_c5_size(oracle):
+    """BASELINE config C5 at full size: 256 pairs x (4096 x 4096 SIFT-128, 2048 hypotheses), three lanes; eight distinct
+    pairs cycled, a sample of the results checked bit for bit against the oracle and every repeat against its twin."""
+    n, Hc, distinct, pairs = 4096, 2048, 8, 256
+    ws = [synth.pair_workload(n, n, 128, seed=0xC5 + i, kind="sift") for i in range(distinct)]
+    b = pm.api.PairBatch(0, 3, n, n, 128)
+    jobs = [(ws[j % distinct]["q"].ctypes.data, n, ws[j % distinct]["t"].ctypes.data, n,
+             ws[j % distinct]["kp1"].ctypes.data, ws[j % distinct]["kp2"].ctypes.data) for j in range(pairs)]
+    res, good, masks = b.run(jobs, RATIO, Hc, TAU, 0x5EED, knn_flags=pm.api.PM_KNN_HINT_INTEGER, want_good=True, want_masks=True)
+    b.close()
+    for j in range(distinct, pairs):            # same inputs => same answer, whatever lane and position
+        a, c = res[j], res[j % distinct]
+        assert (a.best_key, a.n_good, a.n_inliers, bytes(a.F)) == (c.best_key, c.n_good, c.n_inliers, bytes(c.F)), j
+    for j in (0, 5, 131, 255):
+        w = ws[j % distinct]
+        g_o = oracle.filter_ratio(oracle.bf_knn_l2(w["q"], w["t"], 2, nthreads=8), RATIO)
+        rc_o, F_o, mask_o, ninl_o, key_o = oracle.ransac_fundamental(w["kp1"][g_o["queryIdx"]], w["kp2"][g_o["trainIdx"]],
+                                                                     Hc, TAU, 0x5EED, nthreads=8)
+        r = res[j]
+        assert r.n_good == g_o.size and r.status == rc_o == 0 and r.best_key == key_o and r.n_inliers == ninl_o, j
+        assert (good[j, :r.n_good]["trainIdx"] == g_o["trainIdx"]).all() and (good[j, :r.n_good]["queryIdx"] == g_o["queryIdx"]).all()
+        assert (np.array(r.F[:]).view(np.uint64) == F_o.reshape(9).view(np.uint64)).all(), j
+        assert (masks[j, :r.n_good] == mask_o).all(), j
