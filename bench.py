@@ -35,12 +35,25 @@ PEAK_F32_VALU_TFLOPS = 157.3
 PEAK_F16_MFMA_TFLOPS = 2500.0    # dense f16/bf16 MFMA (spec; the 5 PF headline includes 2:1 sparsity)
 
 
+def _kernel_source_sha():
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("knn_coarse.hip", "knn_shared.hpp", "knn_l2.hip", "knn_hamming.hip"):
+        with open(os.path.join(ROOT, "points_matching_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(key, nq, nt):
-    """HBM bytes per launch of the dominant kernel, from the committed PMC passes (profiles/r01_traffic.json:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction applied).  PMC counters cannot be
-    read from inside this process, so the figure is the profiled one for exactly this workload, else null."""
+    """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from inside this process: the figure
+    comes from the committed rocprofv3 --pmc passes (profiles/r02_traffic.json: FETCH_SIZE / WRITE_SIZE in separate
+    runs, gfx950 correction applied) and is used ONLY when that file is stamped with the hash of the kernel sources
+    it was measured on and this is exactly the profiled workload; otherwise null."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"]
+        doc = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+        t = doc["kernels"]
+        if doc.get("kernel_source_sha16") != _kernel_source_sha():
+            return None
     except (OSError, ValueError, KeyError):
         return None
     want = {"c3:knn_l2_mfma_f16": (8192, 8192), "c3_f32:knn_l2_mfma": (8192, 8192), "c4:knn_hamming_mfma_i8": (32768, 32768)}
@@ -160,16 +173,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--nq", type=int, default=8192)
-    ap.add_argument("--nt", type=int, default=8192)
+    ap.add_argument("--nq", type=int, default=None, help="query rows (default: the workload's)")
+    ap.add_argument("--nt", type=int, default=None, help="train rows (default: the workload's)")
     ap.add_argument("--dim", type=int, default=128)
-    ap.add_argument("--hyps", type=int, default=10000)
+    ap.add_argument("--hyps", type=int, default=None, help="RANSAC hypotheses (default: the workload's)")
     ap.add_argument("--kind", default="sift", choices=["sift", "surf", "orb"],
                     help="descriptor family: sift (u8-valued f32, BASELINE C3), surf (general f32), orb (256-bit, C4)")
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5"],
                     help="BASELINE config: c3 (default, headline), c2 = 2k x 2k SIFT latency case, "
                          "c4 = 32k x 32k ORB-256 + 100k hypotheses (per GPU: the multi-GPU run shards it), "
                          "c5 = batch of 256 image pairs x 4k descriptors streamed end to end (pairs sharded over ranks)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = every rank matches its own nq query rows (global problem N*nq x nt, the default); "
+                         "strong = ONE nq x nt problem, query rows and hypothesis ids both cut N ways (BASELINE config 4 is "
+                         "`--workload c4 --scaling strong`)")
+    ap.add_argument("--sustain-seconds", type=float, default=0.5,
+                    help="after the K timed steps: back-to-back steps for at least this long (clock-sustained figure)")
     ap.add_argument("--pairs", type=int, default=256, help="c5: image pairs in the whole job")
     ap.add_argument("--lanes", type=int, default=3, help="c5: streams (lanes) per GPU")
     ap.add_argument("--exercise-exchange", action="store_true",
@@ -225,18 +244,30 @@ def main():
 
     if args.workload == "c5":
         return bench_c5(args, world, rank, local_rank, dev, multi, saved_stdout)
-    if args.workload == "c2":
-        args.nq = args.nt = 2048
-    elif args.workload == "c4":
-        args.nq = args.nt = 32768
-        args.kind, args.dim, args.hyps = "orb", 32, 100000
-    nq, nt, dim, H, K = args.nq, args.nt, args.dim, args.hyps, 2
+    wl_n, wl_h = {"c2": (2048, 10000), "c3": (8192, 10000), "c4": (32768, 100000)}[args.workload]
+    if args.workload == "c4":
+        args.kind, args.dim = "orb", 32
+    nq = args.nq if args.nq else wl_n
+    nt = args.nt if args.nt else wl_n
+    dim, H, K = args.dim, args.hyps if args.hyps else wl_h, 2
     hamming = args.kind == "orb"
     ratio, thresh, seed = 0.8, 1.0, 0x5EED
     # A SIFT matcher knows its descriptors are u8-valued floats: state it, so that only the exact
     # f16-MFMA coarse route is enqueued (the claim is verified on the device).  Other kinds: auto.
     knn_flags = pm.api.PM_KNN_HINT_INTEGER if args.kind == "sift" else 0
-    w = synth.pair_workload(nq, nt, dim, seed=0xC4 if hamming else 0xC3, rank=rank, kind=args.kind)
+    wseed = 0xC4 if hamming else 0xC3
+    nq_total = nq
+    if args.scaling == "strong" and world > 1:
+        # ONE problem: every rank builds it and keeps its contiguous block of query rows (train set replicated)
+        if nq % world:
+            raise SystemExit("bench.py: --scaling strong needs nq divisible by the number of ranks")
+        w = synth.pair_workload(nq, nt, dim, seed=wseed, rank=0, kind=args.kind)
+        nq = nq // world
+        w["q"] = np.ascontiguousarray(w["q"][rank * nq:(rank + 1) * nq])
+        w["kp1"] = np.ascontiguousarray(w["kp1"][rank * nq:(rank + 1) * nq])
+    else:
+        w = synth.pair_workload(nq, nt, dim, seed=wseed, rank=rank, kind=args.kind)
+        nq_total = nq * world
 
     ctx = pm.Context(local_rank)
     stream = torch.cuda.Stream(device=dev)      # a real (non-null) stream shared by torch and the library
@@ -322,6 +353,33 @@ def main():
     key = int(d_key.item())
     n_inl = int(d_ninl.item())
 
+    # ---- sustained leg: the K timed steps above last a millisecond or two, during which the chip still holds its
+    # boost clock; >= --sustain-seconds of back-to-back steps show the figure it sustains (DVFS give-back)
+    sustained = None
+    if args.sustain_seconds > 0:
+        n_sus = max(args.steps, int(args.sustain_seconds / max(ms_per_step * 1e-3, 1e-6)) + 1)
+        es = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ms_acc, cnt = 0.0, 0
+        fence()
+        t0 = time.perf_counter()
+        for i in range(n_sus):
+            last = i >= n_sus - args.steps          # stage split measured on the last K steps of the run
+            if last:
+                ev2 = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                step(ev2)
+                es.append(ev2)
+            else:
+                step()
+        fence()
+        t_sus = time.perf_counter() - t0
+        m_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in es[2:]]))
+        if multi:
+            tt = torch.tensor([t_sus, m_ms], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_sus, m_ms = [float(x) for x in tt.tolist()]
+        sustained = {"seconds": t_sus, "steps": n_sus, "ms_per_step": t_sus / n_sus * 1e3, "match_ms": m_ms,
+                     "value": float(nq_total) * nt / (m_ms * 1e-3)}
+
     # ---- per-kernel durations: instrumented replay of the same K steps (hipEvents on the stream
     # the kernels run on, recorded inside the library around each launch)
     ctx.timing_enable(True)
@@ -356,6 +414,39 @@ def main():
         ctx.bf_knn_l2_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, K, d_knn.data_ptr(), knn_flags)
         fence()
 
+    # ---- the same matcher stage on GENERAL floats (SURF-like unit-norm descriptors, what main.cpp:37-40 produces):
+    # automatic route -> f32-input MFMA coarse pass.  Reported next to `value` (which is the u8-valued SIFT case).
+    general = None
+    if not hamming and args.kind == "sift" and args.workload in ("c2", "c3"):
+        wg = synth.pair_workload(nq, nt, dim, seed=wseed, rank=rank, kind="surf")
+        g_q = torch.from_numpy(np.ascontiguousarray(wg["q"])).to(dev)
+        g_t = torch.from_numpy(np.ascontiguousarray(wg["t"])).to(dev)
+        g_n = torch.zeros(1, dtype=torch.int32, device=dev)
+
+        def gstep():
+            ctx.bf_knn_l2_dev(g_q.data_ptr(), nq, g_t.data_ptr(), nt, dim, K, d_knn.data_ptr(), 0)
+            ctx.filter_ratio_gather_dev(d_knn.data_ptr(), nq, K, ratio, d_kp1.data_ptr(), d_kp2.data_ptr(),
+                                        d_good.data_ptr(), d_xy1.data_ptr(), d_xy2.data_ptr(), g_n.data_ptr())
+        for _ in range(args.warmup):
+            gstep()
+        fence()
+        ge = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ge[0].record(stream)
+        for _ in range(args.steps):
+            gstep()
+        ge[1].record(stream)
+        fence()
+        g_ms = ge[0].elapsed_time(ge[1]) / args.steps
+        if multi:
+            tt = torch.tensor([g_ms], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            g_ms = float(tt.item())
+        general = {"value": float(nq_total) * nt / (g_ms * 1e-3), "match_ms": g_ms, "matches": int(g_n.item()),
+                   "descriptors": "surf (unit-norm general floats), automatic route (f32-input MFMA coarse pass)"}
+        # leave the arena and the survivor block in the state of the headline workload
+        step()
+        fence()
+
     # ---- parity spot check against the CPU oracle (untimed; checker only)
     parity = "skipped"
     if not args.no_verify and rank == 0:
@@ -385,7 +476,7 @@ def main():
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)
 
-    pairs = float(nq) * nt * world
+    pairs = float(nq_total) * nt
     value = pairs / (match_ms * 1e-3)
     hyp_per_s = H / (rest_ms * 1e-3)
 
@@ -393,7 +484,8 @@ def main():
         "metric": "descriptor-pair distances/s (BF-%s 2-NN + ratio stage); RANSAC hypotheses/s in `ransac`"
                   % ("Hamming" if hamming else "L2"),
         "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
+        "vs_baseline": None,
         "dtype": "u8" if hamming else "f32",
         "dtype_note": "u8 bit strings; coarse pass i8xi8->i32 MFMA on +-1 expanded bits (exact), refinement u32 xor/popcount"
                       if hamming else ("f32 in/out; coarse pass f16xf16->f32 MFMA (exact for u8-valued data), refinement f32"
@@ -402,7 +494,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": "%s: %dx%d %s BF-%s 2-NN + ratio 0.8 + %d-hypothesis RANSAC-F (8-point, "
                                "Sampson, tau=1px) per image pair; N>1: query rows and hypothesis ids sharded"
-                               % (args.workload.upper(), nq, nt,
+                               % (args.workload.upper(), nq_total if args.scaling == "strong" else nq, nt,
                                   "ORB-%d binary" % (8 * dim) if hamming else "SIFT-%d f32" % dim,
                                   "Hamming" if hamming else "L2", H), "descriptors": args.kind, "k": K,
                    "coarse_route": "n/a (Hamming)" if hamming else
@@ -412,6 +504,11 @@ def main():
                    "best_hyp": pm.api.ransac_key_hyp(key) if key else None},
         "kernels_us": kern, "knn_refine": kstats, "parity": parity,
     }
+    if general:
+        out["value_general_floats"] = general["value"]
+        out["general_floats"] = general
+    if sustained:
+        out["sustained"] = sustained
     # roofline of the dominant kernel (algorithmic 2*D flop per descriptor pair)
     flops = 2.0 * dim * nq * nt
     if hamming and "knn_hamming_mfma_i8" in kern:
@@ -452,8 +549,9 @@ def main():
                            "algorithmic_bytes": (nq + nt) * dim * 4 + nq * K * 16,
                            "dtype": "f32-input MFMA (v_mfma_f32_32x32x2_f32)"}
     if out.get("roofline", {}).get("traffic") is not None:
-        out["roofline"]["traffic_source"] = "profiles/r01_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this " \
-                                            "kernel on this workload (separate passes, gfx950 correction); not re-measured live"
+        out["roofline"]["traffic_source"] = "profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this kernel " \
+                                            "on this workload, separate passes, gfx950 correction), stamped with the hash of " \
+                                            "the kernel sources it was measured on: " + _kernel_source_sha()
     if f32_route_us > 0:
         ach = flops / (f32_route_us * 1e-6) / 1e12
         out["roofline_f32_route"] = {"kernel": "knn_l2_mfma", "bound": "mfma", "achieved": ach,
@@ -473,36 +571,45 @@ def main():
 
     if world == 1 and not args.no_cpu_baseline:
         from oracle import pm_oracle as O
-        sample_q = min(nq, 2048)
-        t0 = time.perf_counter()
         knn_cpu = O.bf_knn_hamming if hamming else O.bf_knn_l2
-        m = knn_cpu(w["q"][:sample_q], w["t"], K, nthreads=1)
-        t_knn = time.perf_counter() - t0
-        nth = max(1, min(os.cpu_count() or 1, 16))      # the GPU box gives a 1-GPU job a 16-core share
-        t0 = time.perf_counter()
-        good = O.filter_ratio(knn_cpu(w["q"], w["t"], K, nthreads=nth), ratio)
-        t_knn_all = time.perf_counter() - t0
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            avail = os.cpu_count() or 1
+        nth = max(1, avail)                             # every core this job may run on
+
+        def best_of(fn, reps):
+            best = None
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                r = fn()
+                dt = time.perf_counter() - t0
+                best = dt if best is None or dt < best else best
+            return best, r
+        # 1 thread: the FULL matcher and the full RANSAC run (bounded: a few seconds at C3; C4's 1e9 pairs are sampled)
+        sample_q = nq if float(nq) * nt <= 1.5e8 * 20 else max(256, int(1.5e8 * 20 / nt))
+        t_knn, _ = best_of(lambda: knn_cpu(w["q"][:sample_q], w["t"], K, nthreads=1), 1)
+        t_knn_all, knn_all = best_of(lambda: knn_cpu(w["q"], w["t"], K, nthreads=nth), 3)
+        good = O.filter_ratio(knn_all, ratio)
         xs1 = O.gather_points(w["kp1"], good["queryIdx"])
         xs2 = O.gather_points(w["kp2"], good["trainIdx"])
-        t0 = time.perf_counter()
-        O.ransac_fundamental(xs1, xs2, H, thresh, seed, nthreads=1)
-        t_r = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        O.ransac_fundamental(xs1, xs2, H, thresh, seed, nthreads=nth)
-        t_r_all = time.perf_counter() - t0
+        Hs = H if float(H) * max(good.size, 1) <= 4e9 else max(1000, int(4e9 / max(good.size, 1)))
+        t_r, _ = best_of(lambda: O.ransac_fundamental(xs1, xs2, Hs, thresh, seed, nthreads=1), 1)
+        t_r_all, _ = best_of(lambda: O.ransac_fundamental(xs1, xs2, H, thresh, seed, nthreads=nth), 3)
         try:
             cpu_model = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
         except (OSError, IndexError):
             cpu_model = "unknown"
         out["cpu_baseline"] = {
             "value": sample_q * nt / t_knn, "unit": "pairs/s", "cores": 1, "kind": "port",
-            "sample": "oracle (CPU restatement, AVX2-vectorised by gcc, 1 thread): matcher on the first %d of %d "
-                      "query rows x %d train rows; RANSAC-F on the full %d hypotheses x %d matches"
-                      % (sample_q, nq, nt, H, good.size),
-            "ransac_hyp_per_s": H / t_r, "host_cpus": os.cpu_count(), "cpu_model": cpu_model,
-            "threads_%d" % nth: {"value": float(nq) * nt / t_knn_all, "ransac_hyp_per_s": H / t_r_all, "cores": nth,
-                                 "sample": "full %d x %d matcher and the full RANSAC run, OpenMP over query rows / "
-                                           "hypothesis ids" % (nq, nt)},
+            "sample": "oracle (CPU restatement of the path, gcc -O3 AVX2, 1 thread): matcher on %d of %d query rows x %d "
+                      "train rows; RANSAC-F on %d of %d hypotheses x %d matches"
+                      % (sample_q, nq, nt, Hs, H, good.size),
+            "ransac_hyp_per_s": Hs / t_r, "host_cpus": os.cpu_count(), "cpus_available_to_this_job": avail,
+            "cpu_model": cpu_model,
+            "all_cores": {"value": float(nq) * nt / t_knn_all, "ransac_hyp_per_s": H / t_r_all, "cores": nth,
+                          "sample": "full %d x %d matcher and the full RANSAC run, OpenMP over query rows / hypothesis ids, "
+                                    "best of 3, %d threads = every core in this job's affinity mask" % (nq, nt, nth)},
         }
     print(json.dumps(out))
     if multi:
