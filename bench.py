@@ -576,7 +576,27 @@ def main():
             avail = len(os.sched_getaffinity(0))
         except (AttributeError, OSError):
             avail = os.cpu_count() or 1
-        nth = max(1, avail)                             # every core this job may run on
+        # the CPU share of this job: the cgroup quota when there is one (a 1-GPU job on the pool gets 16 cores of a
+        # 256-thread host; running 256 OpenMP threads inside that quota is 4x SLOWER than 16), else the affinity mask
+        quota = None
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if q != "max":
+                quota = max(1, int(float(q) / float(per) + 0.5))
+        except (OSError, ValueError):
+            try:
+                q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    quota = max(1, int(q / per + 0.5))
+            except (OSError, ValueError):
+                pass
+        share = min(avail, quota) if quota else avail
+        # all-cores leg: the job's share, and (when the mask is wider than that and no quota is visible) a probe of a
+        # few thread counts, keeping the fastest — the number reported is the best the host cores gave this job
+        cands = sorted({share} | ({16, 32, 64} if quota is None and avail > 16 else set()))
+        cands = [c for c in cands if c <= avail]
+        nth = cands[0]
 
         def best_of(fn, reps):
             best = None
@@ -589,7 +609,11 @@ def main():
         # 1 thread: the FULL matcher and the full RANSAC run (bounded: a few seconds at C3; C4's 1e9 pairs are sampled)
         sample_q = nq if float(nq) * nt <= 1.5e8 * 20 else max(256, int(1.5e8 * 20 / nt))
         t_knn, _ = best_of(lambda: knn_cpu(w["q"][:sample_q], w["t"], K, nthreads=1), 1)
-        t_knn_all, knn_all = best_of(lambda: knn_cpu(w["q"], w["t"], K, nthreads=nth), 3)
+        t_knn_all, knn_all = None, None
+        for c in cands:
+            tc, rc_ = best_of(lambda c=c: knn_cpu(w["q"], w["t"], K, nthreads=c), 3)
+            if t_knn_all is None or tc < t_knn_all:
+                t_knn_all, knn_all, nth = tc, rc_, c
         good = O.filter_ratio(knn_all, ratio)
         xs1 = O.gather_points(w["kp1"], good["queryIdx"])
         xs2 = O.gather_points(w["kp2"], good["trainIdx"])
@@ -605,11 +629,12 @@ def main():
             "sample": "oracle (CPU restatement of the path, gcc -O3 AVX2, 1 thread): matcher on %d of %d query rows x %d "
                       "train rows; RANSAC-F on %d of %d hypotheses x %d matches"
                       % (sample_q, nq, nt, Hs, H, good.size),
-            "ransac_hyp_per_s": Hs / t_r, "host_cpus": os.cpu_count(), "cpus_available_to_this_job": avail,
+            "ransac_hyp_per_s": Hs / t_r, "host_cpus": os.cpu_count(), "affinity_cpus": avail, "cgroup_cpu_quota": quota,
             "cpu_model": cpu_model,
             "all_cores": {"value": float(nq) * nt / t_knn_all, "ransac_hyp_per_s": H / t_r_all, "cores": nth,
                           "sample": "full %d x %d matcher and the full RANSAC run, OpenMP over query rows / hypothesis ids, "
-                                    "best of 3, %d threads = every core in this job's affinity mask" % (nq, nt, nth)},
+                                    "best of 3, %d threads (the job's CPU share: cgroup quota if any, else the fastest of %s threads)"
+                                    % (nq, nt, nth, cands)},
         }
     print(json.dumps(out))
     if multi:
