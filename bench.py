@@ -8,9 +8,9 @@ on the ~2.3k surviving matches.  It carries BOTH halves of BASELINE.json's metri
 launch-latency sized and is covered as a parity test instead.
 
 One step = one pass of the path over one image pair, everything resident in HBM:
-  pm_bf_knn_l2_f32_dev -> pm_filter_ratio_gather_dev -> pm_ransac_score_devn
-  -> [N>1: all-gather of survivors before RANSAC, 8-byte all-reduce(max) of the key after]
-  -> pm_ransac_model_from_key_dev (F + inlier mask of the winner)
+  pm_bf_knn_l2_ratio_dev (2-NN + ratio test + compaction + gather) -> pm_ransac_run_dev (one launch: sample, solve,
+  score, pick, mask);  N>1: -> all-gather of the survivor blocks -> pm_ransac_shard_parts_dev -> all-gather of the
+  80-byte (key, F) records -> pm_ransac_finish_parts_dev (F + inlier mask of the winner on every rank)
 N GPUs (weak scaling): rank r matches its own 8k query rows against the replicated 8k train
 rows (global problem = N*8k x 8k), the survivors are all-gathered (RCCL), every rank scores its
 shard of the 10k hypothesis ids over ALL gathered correspondences, one all-reduce(max) of the
@@ -309,10 +309,12 @@ def main():
             e[0].record(stream)
         if hamming:
             ctx.bf_knn_hamming_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, K, d_knn.data_ptr())
-        else:
-            ctx.bf_knn_l2_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, K, d_knn.data_ptr(), knn_flags)
-        ctx.filter_ratio_gather_dev(d_knn.data_ptr(), nq, K, ratio, d_kp1.data_ptr(), d_kp2.data_ptr(),
-                                    d_good.data_ptr(), d_xy1.data_ptr(), d_xy2.data_ptr(), d_n.data_ptr())
+            ctx.filter_ratio_gather_dev(d_knn.data_ptr(), nq, K, ratio, d_kp1.data_ptr(), d_kp2.data_ptr(),
+                                        d_good.data_ptr(), d_xy1.data_ptr(), d_xy2.data_ptr(), d_n.data_ptr())
+        else:       # 2-NN + ratio test + compaction + keypoint gather: one call, the filter rides the refinement launch
+            ctx.bf_knn_l2_ratio_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, knn_flags, ratio, d_kp1.data_ptr(),
+                                    d_kp2.data_ptr(), d_knn.data_ptr(), d_good.data_ptr(), d_xy1.data_ptr(), d_xy2.data_ptr(),
+                                    d_n.data_ptr())
         if e:
             e[1].record(stream)
         if multi:
@@ -424,9 +426,8 @@ def main():
         g_n = torch.zeros(1, dtype=torch.int32, device=dev)
 
         def gstep():
-            ctx.bf_knn_l2_dev(g_q.data_ptr(), nq, g_t.data_ptr(), nt, dim, K, d_knn.data_ptr(), 0)
-            ctx.filter_ratio_gather_dev(d_knn.data_ptr(), nq, K, ratio, d_kp1.data_ptr(), d_kp2.data_ptr(),
-                                        d_good.data_ptr(), d_xy1.data_ptr(), d_xy2.data_ptr(), g_n.data_ptr())
+            ctx.bf_knn_l2_ratio_dev(g_q.data_ptr(), nq, g_t.data_ptr(), nt, dim, 0, ratio, d_kp1.data_ptr(), d_kp2.data_ptr(),
+                                    d_knn.data_ptr(), d_good.data_ptr(), d_xy1.data_ptr(), d_xy2.data_ptr(), g_n.data_ptr())
         for _ in range(args.warmup):
             gstep()
         fence()

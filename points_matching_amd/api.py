@@ -35,7 +35,7 @@ EXPORTS = [
     "pm_filter_ratio_gather_dev", "pm_filter_midpoint_gather_dev", "pm_concat_points_dev",
     "pm_ransac_fundamental", "pm_ransac_score_dev", "pm_ransac_score_devn", "pm_ransac_model_from_hyp",
     "pm_ransac_model_from_key_dev", "pm_ransac_run_dev", "pm_ransac_shard_parts_dev", "pm_ransac_finish_parts_dev",
-    "pm_ctx_set_option", "pm_ctx_get_option",
+    "pm_ctx_set_option", "pm_ctx_get_option", "pm_bf_knn_l2_ratio_dev",
     "pm_mgpu_create", "pm_mgpu_destroy", "pm_mgpu_size", "pm_mgpu_ctx", "pm_mgpu_ransac_fundamental", "pm_mgpu_match_ransac",
     "pm_batch_create", "pm_batch_destroy", "pm_batch_run", "pm_host_register", "pm_host_unregister",
     "pm_lmeds_fundamental", "pm_lmeds_fundamental_dev", "pm_lmeds_default_iters", "pm_ransac7_adaptive",
@@ -62,7 +62,7 @@ class PointsView(C.Structure):
 
 RANSAC_RECORD_DTYPE = np.dtype([("key", "<u8"), ("F", "<f8", (9,))])       # pm_ransac_record, 80 bytes
 PM_MAX_PARTS = 64
-PM_OPT_RANSAC_PATH, PM_OPT_SCORE_OPERANDS, PM_OPT_HAMMING_ROUTE, PM_OPT_KNN_F16_WAVES = 1, 2, 3, 4
+PM_OPT_RANSAC_PATH, PM_OPT_SCORE_OPERANDS, PM_OPT_HAMMING_ROUTE, PM_OPT_KNN_F16_WAVES, PM_OPT_FILTER_FUSION = 1, 2, 3, 4, 5
 
 
 _lib = None
@@ -312,6 +312,13 @@ class Context:
     def bf_knn_l2_dev(self, dq_ptr, nq, dt_ptr, nt, dim, k, dout_ptr, flags=0):
         _check(lib().pm_bf_knn_l2_f32_dev(self._h, C.c_void_p(dq_ptr), nq, C.c_void_p(dt_ptr), nt,
                                           dim, k, flags, C.c_void_p(dout_ptr)))
+
+    def bf_knn_l2_ratio_dev(self, dq_ptr, nq, dt_ptr, nt, dim, flags, ratio, dkp1_ptr, dkp2_ptr, dknn_ptr, dgood_ptr,
+                            dxy1_ptr, dxy2_ptr, dn_ptr):
+        _check(lib().pm_bf_knn_l2_ratio_dev(self._h, C.c_void_p(dq_ptr), nq, C.c_void_p(dt_ptr), nt, dim, flags,
+                                            C.c_float(ratio), C.c_void_p(dkp1_ptr or 0), C.c_void_p(dkp2_ptr or 0),
+                                            C.c_void_p(dknn_ptr or 0), C.c_void_p(dgood_ptr), C.c_void_p(dxy1_ptr or 0),
+                                            C.c_void_p(dxy2_ptr or 0), C.c_void_p(dn_ptr)))
 
     def bf_knn_hamming(self, q, t, k):
         q = np.ascontiguousarray(q, np.uint8)

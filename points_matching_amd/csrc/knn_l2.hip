@@ -337,20 +337,50 @@ __device__ __forceinline__ float l2sqr_canonical_coop8(const float* __restrict__
     return d;
 }
 
+// Ratio test + stable compaction + keypoint gather (main.cpp:49-69 in its ratio form, :77-78, :89-91) fused into the
+// refinement launch.  Tiles of 32 queries = 8 workgroups.  A workgroup adds (1 << 32 | its 4 keep bits) to the tile's
+// arrival word with ONE agent-scope atomic; the workgroup whose add completes the tile owns the tile's compaction: it
+// publishes the tile's survivor count (epoch-tagged, so nothing is ever cleared), sums the counts of the tiles before it
+// (decoupled look-back: one polling lane per earlier tile; earlier tiles belong to earlier workgroups, which the
+// dispatcher started first) and writes the tile's survivors at prefix + rank.  What it needs from the other seven
+// workgroups — nearest neighbour and distance of each query — reaches it as one 8-byte write-through store per query
+// (agent scope, drained before the arrival add), read back with agent-scope loads.
+struct KnnFuse {
+    float ratio;
+    const float* kp1;             // may be null together with kp2 / xy1 / xy2: match list only
+    const float* kp2;
+    pm_match* good;
+    float* xy1;
+    float* xy2;
+    int* n_out;
+    unsigned long long* pk;       // [nq] (distance bits << 32) | trainIdx of the nearest neighbour
+    unsigned long long* tile;     // [tiles] arrival word: arrivals << 32 | 32 keep bits; back to 0 when the tile is taken
+    unsigned* tilecnt;            // [tiles] epoch << 8 | survivors (epoch-tagged, never cleared)
+    unsigned* err;                // set to the epoch if a look-back gave up (never observed; reported by pm_ctx_knn_stats)
+    unsigned epoch;
+};
+constexpr int KF_TILE_BLOCKS = 8;                 // workgroups (of 4 queries) per tile
+constexpr unsigned KF_SPIN_LIMIT = 1u << 22;
+
 // NS = candidate-list entries a lane holds (ceil(slots / 64) rounded up to 1, 2, 4 or 8): the slot
 // values are read ONCE into registers, the candidates of all lists are compacted into one per-wave
 // LDS list and evaluated together (8 rows per round), so neither the number of lists nor the way the
 // candidates spread over them adds rounds.  (This kernel is VALU-issue bound: one wave per query.)
-template <bool VEC4, int NS>
+template <bool VEC4, int NS, bool FUSE>
 __global__ __launch_bounds__(256) void knn_l2_refine(
     const float* __restrict__ Q, const float* __restrict__ T, const float* __restrict__ qnorm,
     const unsigned long long* __restrict__ stats, unsigned epoch, unsigned* __restrict__ diag, int nq, int nt,
-    int dim, int k, KnnGeom g16, KnnGeom g32, int route, pm_match* __restrict__ out)
+    int dim, int k, KnnGeom g16, KnnGeom g32, int route, pm_match* __restrict__ out, KnnFuse fz)
 {
     __shared__ int clist[4][64 * NS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
-    if (q >= nq) return;                                     // wave-uniform; no block barriers below
+    int q = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    bool ghost = false;                                      // FUSE: waves past the last query stay for the barriers
+    if (q >= nq) {                                           // wave-uniform
+        if (!FUSE) return;                                   // (no block barriers below without FUSE)
+        ghost = true;
+        q = nq - 1;
+    }
     const float* qp = Q + static_cast<size_t>(q) * dim;
     const float na = qnorm[q];
     const unsigned long long s0 = stats[0], s1 = stats[1];
@@ -400,7 +430,7 @@ __global__ __launch_bounds__(256) void knn_l2_refine(
 
     // Non-finite inputs (or a window that is not finite) void the coarse ranking: scan everything.
     const bool rescan = nonfinite || !(thr < KNN_INF);
-    if (diag && lane == 0) { if (rescan) atomicAdd(&diag[0], 1u); if (nonfinite) diag[1] = 1u; }
+    if (diag && lane == 0 && !ghost) { if (rescan) atomicAdd(&diag[0], 1u); if (nonfinite) diag[1] = 1u; }
 
     Best2 b{~0ull, ~0ull, KNN_INF, KNN_INF};
     if (!rescan) {
@@ -421,7 +451,7 @@ __global__ __launch_bounds__(256) void knn_l2_refine(
             const unsigned long long cand = __ballot(is_cand);
             if (is_cand) clist[wave][total + __popcll(cand & ((1ull << lane) - 1ull))] = j;
             total += __popcll(cand);
-            if (diag && lane == 0 && spilled) atomicAdd(&diag[0], static_cast<unsigned>(__popcll(spilled)));
+            if (diag && lane == 0 && spilled && !ghost) atomicAdd(&diag[0], static_cast<unsigned>(__popcll(spilled)));
             while (spilled) {                               // wave-uniform, rare: every row of that split
                 const int split = (64 * i + __ffsll(static_cast<long long>(spilled)) - 1) / KNN_C;
                 spilled &= spilled - 1ull;
@@ -460,21 +490,97 @@ __global__ __launch_bounds__(256) void knn_l2_refine(
             best2_insert(b, knn_key(d, j), d);
         }
     }
+    int nn_idx[2] = {-1, -1};                                // wave-uniform copies of the first two neighbours (FUSE)
+    float nn_d[2] = {KNN_INF, KNN_INF};
     for (int c = 0; c < k; ++c) {
         const uint64_t best = wave_min_u64(b.k0);
         const unsigned long long owners = __ballot(b.k0 == best);
         const int first = __ffsll(static_cast<long long>(owners)) - 1;
         const float dist = __shfl(b.d0, first, 64);
         if (lane == first) { b.k0 = b.k1; b.d0 = b.d1; b.k1 = ~0ull; b.d1 = KNN_INF; }
+        pm_match m;
+        m.queryIdx = q;
+        m.imgIdx = 0;
+        if (best == ~0ull) { m.trainIdx = -1; m.distance = KNN_INF; }
+        else { m.trainIdx = static_cast<int>(static_cast<uint32_t>(best)); m.distance = dist; }
+        if (c < 2) { nn_idx[c] = m.trainIdx; nn_d[c] = m.distance; }
+        if (lane == 0 && !ghost && out) out[static_cast<size_t>(q) * k + c] = m;
+    }
+    if (!FUSE) return;
+
+    // ---- ratio test + stable compaction + gather, in this launch (see KnnFuse)
+    __shared__ unsigned s_keep[4];
+    __shared__ unsigned s_bits;
+    __shared__ int s_last;
+    __shared__ int s_pre[4];
+    const int tid = threadIdx.x;
+    {
+        const float rhs = fz.ratio * nn_d[1];                // pm_filter_ratio: float multiply, strict <
+        const bool keep = !ghost && nn_idx[0] >= 0 && nn_idx[1] >= 0 && nn_d[0] < rhs;
         if (lane == 0) {
-            pm_match m;
-            m.queryIdx = q;
-            m.imgIdx = 0;
-            if (best == ~0ull) { m.trainIdx = -1; m.distance = KNN_INF; }
-            else { m.trainIdx = static_cast<int>(static_cast<uint32_t>(best)); m.distance = dist; }
-            out[static_cast<size_t>(q) * k + c] = m;
+            if (!ghost)
+                __hip_atomic_store(&fz.pk[q], (static_cast<unsigned long long>(f32_bits(nn_d[0])) << 32) |
+                                                  static_cast<unsigned long long>(static_cast<uint32_t>(nn_idx[0])),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_keep[wave] = keep ? 1u : 0u;
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's 8-byte record is written through
+    __syncthreads();
+    const int blk = static_cast<int>(blockIdx.x), tile = blk / KF_TILE_BLOCKS;
+    const int nblk = static_cast<int>(gridDim.x), ntiles = (nblk + KF_TILE_BLOCKS - 1) / KF_TILE_BLOCKS;
+    if (tid == 0) {
+        const unsigned bits4 = s_keep[0] | (s_keep[1] << 1) | (s_keep[2] << 2) | (s_keep[3] << 3);
+        const unsigned long long add = (1ull << 32) | (static_cast<unsigned long long>(bits4) << (4 * (blk % KF_TILE_BLOCKS)));
+        const unsigned long long old = __hip_atomic_fetch_add(&fz.tile[tile], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int in_tile = nblk - tile * KF_TILE_BLOCKS < KF_TILE_BLOCKS ? nblk - tile * KF_TILE_BLOCKS : KF_TILE_BLOCKS;
+        const bool last = static_cast<int>(old >> 32) == in_tile - 1;
+        s_last = last ? 1 : 0;
+        if (last) {
+            s_bits = static_cast<unsigned>(old + add);
+            __hip_atomic_store(&fz.tile[tile], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
+        }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const unsigned bits = s_bits;
+    const int cnt = __popc(bits);
+    if (tid == 0)
+        __hip_atomic_store(&fz.tilecnt[tile], (fz.epoch << 8) | static_cast<unsigned>(cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int before = 0;
+    for (int j = tid; j < tile; j += 256) {
+        unsigned v = 0u, spins = 0u;
+        for (;;) {
+            v = __hip_atomic_load(&fz.tilecnt[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((v >> 8) == fz.epoch || ++spins > KF_SPIN_LIMIT) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if ((v >> 8) == fz.epoch) before += static_cast<int>(v & 255u);
+        else __hip_atomic_store(fz.err, fz.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+    if (lane == 0) s_pre[wave] = before;
+    __syncthreads();
+    const int prefix = s_pre[0] + s_pre[1] + s_pre[2] + s_pre[3];
+    if (tid < 32 && ((bits >> tid) & 1u)) {
+        const int qi = tile * (4 * KF_TILE_BLOCKS) + tid;
+        const int off = prefix + __popc(bits & ((1u << tid) - 1u));
+        const unsigned long long rec = __hip_atomic_load(&fz.pk[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pm_match m;
+        m.queryIdx = qi;
+        m.trainIdx = static_cast<int>(static_cast<uint32_t>(rec));
+        m.imgIdx = 0;
+        m.distance = __uint_as_float(static_cast<uint32_t>(rec >> 32));
+        fz.good[off] = m;
+        if (fz.kp1) {
+            *reinterpret_cast<float2*>(fz.xy1 + 2 * static_cast<size_t>(off)) =
+                *reinterpret_cast<const float2*>(fz.kp1 + 2 * static_cast<size_t>(qi));
+            *reinterpret_cast<float2*>(fz.xy2 + 2 * static_cast<size_t>(off)) =
+                *reinterpret_cast<const float2*>(fz.kp2 + 2 * static_cast<size_t>(m.trainIdx));
+        }
+    }
+    if (tile == ntiles - 1 && tid == 0) *fz.n_out = prefix + cnt;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -672,6 +778,7 @@ __global__ __launch_bounds__(256) void knn_l2_exact(const float* __restrict__ Q,
 int run_exact(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt, int dim, int k, pm_match* dout)
 {
     if (nq == 0) return PM_OK;
+    PM_REQUIRE(dout != nullptr, PM_E_INVALID, "this shape takes the exact kernel, which needs the k-NN record buffer (d_knn)");
     dim3 grid((nq + EXQ_WG - 1) / EXQ_WG);
     pm::ScopedKernelTime t(ctx, "knn_l2_exact");
     if (k == 1)
@@ -684,24 +791,47 @@ int run_exact(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt, int
     return PM_OK;
 }
 
-}  // namespace
 
-extern "C" int pm_bf_knn_l2_f32_dev(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt, int dim,
-                                    int k, int flags, pm_match* dout)
+// per-context words of the fused compaction: arrival word + epoch-tagged survivor count per 32-query tile
+int kf_prepare(pm_ctx* ctx, int nq, KnnFuse& fz)
 {
-    PM_REQUIRE(ctx != nullptr, PM_E_INVALID, "ctx is null");
-    PM_REQUIRE(nq >= 0 && nt >= 0 && dim >= 1 && k >= 1 && k <= PM_MAX_K, PM_E_INVALID,
-               "need nq,nt >= 0, dim >= 1, 1 <= k <= PM_MAX_K");
-    PM_REQUIRE(nq == 0 || (dq && dout), PM_E_INVALID, "null query/output pointer");
-    PM_REQUIRE(nt == 0 || dt, PM_E_INVALID, "null train pointer");
-    if (nq == 0) return PM_OK;
-    PM_HIP_CHECK(hipSetDevice(ctx->device));
+    const int tiles = (nq + 31) / 32;
+    if (tiles > ctx->kf_cap) {
+        PM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (ctx->kf_tile) PM_HIP_CHECK(hipFree(ctx->kf_tile));
+        ctx->kf_tile = nullptr;
+        ctx->kf_cap = 0;
+        const int cap = tiles < 4096 ? 4096 : tiles + tiles / 2;
+        PM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ctx->kf_tile), static_cast<size_t>(cap) * 12));
+        PM_HIP_CHECK(hipMemsetAsync(ctx->kf_tile, 0, static_cast<size_t>(cap) * 12, ctx->stream));
+        ctx->kf_cap = cap;
+        ctx->kf_epoch = 0;
+    }
+    if (++ctx->kf_epoch >= (1u << 24)) {          // 24-bit tag: restart
+        PM_HIP_CHECK(hipMemsetAsync(ctx->kf_tile, 0, static_cast<size_t>(ctx->kf_cap) * 12, ctx->stream));
+        ctx->kf_epoch = 1;
+    }
+    fz.tile = ctx->kf_tile;
+    fz.tilecnt = reinterpret_cast<unsigned*>(ctx->kf_tile + ctx->kf_cap);
+    fz.err = reinterpret_cast<unsigned*>(ctx->knn_stats) + 12;      // byte 48 of the side-band block
+    fz.epoch = ctx->kf_epoch;
+    return PM_OK;
+}
+
+// the matcher; `fuse` (k == 2): ratio test + compaction + gather ride the refinement launch (MFMA routes) or follow as
+// pm_filter_ratio_gather_dev (exact kernel)
+int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt, int dim, int k, int flags, pm_match* dout,
+                   KnnFuse* fuse)
+{
 
     // the MFMA routes read rows as 16-byte vectors: dim % 4 == 0 AND 16-byte aligned base pointers (anything else
     // takes the exact kernel, whose loads are scalar unless both hold)
     const bool aligned16 = ((reinterpret_cast<uintptr_t>(dq) | reinterpret_cast<uintptr_t>(dt)) & 15) == 0;
     const bool fast = !(flags & PM_KNN_FORCE_EXACT) && k <= 2 && (dim % 4) == 0 && dim <= 128 && nt >= 1 && aligned16;
-    if (!fast) return run_exact(ctx, dq, nq, dt, nt, dim, k, dout);
+    if (!fast) {
+        const int rx = run_exact(ctx, dq, nq, dt, nt, dim, k, dout);
+        return rx == PM_OK && fuse ? 1 : rx;                 // 1: done, but the caller still has to filter
+    }
     const int route = (flags & PM_KNN_FORCE_F32) ? ROUTE_F32 : (flags & PM_KNN_HINT_INTEGER) ? ROUTE_F16_HINT : ROUTE_AUTO;
     const bool want32 = route != ROUTE_F16_HINT, want16 = route != ROUTE_F32;
 
@@ -752,8 +882,10 @@ extern "C" int pm_bf_knn_l2_f32_dev(pm_ctx* ctx, const float* dq, int nq, const 
         g16.eps_coef = 0.f;           // integer data: the f16 products and f32 sums are exact
         g16.embed_coef = static_cast<float>(static_cast<double>(1u << lid_bits16) * 1.1920928955078125e-7 * 1.01);
     }
-    if ((want32 && lid_bits32 > 16) || (want16 && lid_bits16 > 16))
-        return run_exact(ctx, dq, nq, dt, nt, dim, k, dout);     // > 64k rows per lane stream
+    if ((want32 && lid_bits32 > 16) || (want16 && lid_bits16 > 16)) {    // > 64k rows per lane stream
+        const int rx = run_exact(ctx, dq, nq, dt, nt, dim, k, dout);
+        return rx == PM_OK && fuse ? 1 : rx;
+    }
 
     // scratch: norms, f16 copies, candidate lists.  The arena is carved per call; callers that
     // interleave calls on one context are serialised by the stream.
@@ -761,8 +893,10 @@ extern "C" int pm_bf_knn_l2_f32_dev(pm_ctx* ctx, const float* dq, int nq, const 
     const size_t c16 = want16 ? sizeof(float) * static_cast<size_t>(nq) * g16.slots : 0;
     const size_t qh = want16 ? sizeof(_Float16) * static_cast<size_t>(nq_pad) * H_ROW : 0;
     const size_t th = want16 ? sizeof(_Float16) * static_cast<size_t>(nt_pad) * H_ROW : 0;
+    const size_t pkb = fuse ? sizeof(unsigned long long) * static_cast<size_t>(nq) : 0;
     const size_t need = pm::align_up(sizeof(float) * nq, 256) + pm::align_up(sizeof(float) * nt, 256) +
-                        pm::align_up(c32, 256) + pm::align_up(c16, 256) + pm::align_up(qh, 256) + pm::align_up(th, 256) + 2048;
+                        pm::align_up(c32, 256) + pm::align_up(c16, 256) + pm::align_up(qh, 256) + pm::align_up(th, 256) +
+                        pm::align_up(pkb, 256) + 2048;
     int rc = pm::arena_reserve(ctx, need);
     if (rc != PM_OK) return rc;
     pm::arena_reset(ctx);
@@ -774,6 +908,14 @@ extern "C" int pm_bf_knn_l2_f32_dev(pm_ctx* ctx, const float* dq, int nq, const 
     _Float16* Th = want16 ? static_cast<_Float16*>(pm::arena_take(ctx, th)) : nullptr;
     PM_REQUIRE(qnorm && tnorm && (!want32 || cval32) && (!want16 || (cval16 && Qh && Th)), PM_E_NOMEM,
                "scratch arena too small");
+    KnnFuse fz{};
+    if (fuse) {
+        fz = *fuse;
+        fz.pk = static_cast<unsigned long long*>(pm::arena_take(ctx, pkb));
+        PM_REQUIRE(fz.pk != nullptr, PM_E_NOMEM, "scratch arena too small");
+        rc = kf_prepare(ctx, nq, fz);
+        if (rc != PM_OK) return rc;
+    }
     g32.cand = cval32;
     g16.cand = cval16;
 
@@ -811,17 +953,68 @@ extern "C" int pm_bf_knn_l2_f32_dev(pm_ctx* ctx, const float* dq, int nq, const 
     {
         pm::ScopedKernelTime t(ctx, "knn_l2_refine");
         const int max_slots = (want16 ? g16.slots : 0) > (want32 ? g32.slots : 0) ? g16.slots : g32.slots;
-#define PM_REFINE(NS_)                                                                                             \
-    hipLaunchKernelGGL((knn_l2_refine<true, NS_>), dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, dq, dt, qnorm, stats, \
-                       epoch, diag, nq, nt, dim, k, g16, g32, route, dout)
+#define PM_REFINE2(NS_, FUSE_)                                                                                     \
+    hipLaunchKernelGGL((knn_l2_refine<true, NS_, FUSE_>), dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, dq, dt, qnorm, \
+                       stats, epoch, diag, nq, nt, dim, k, g16, g32, route, dout, fz)
+#define PM_REFINE(NS_) do { if (fuse) PM_REFINE2(NS_, true); else PM_REFINE2(NS_, false); } while (0)
         if (max_slots <= 64) PM_REFINE(1);
         else if (max_slots <= 128) PM_REFINE(2);
         else if (max_slots <= 256) PM_REFINE(4);
         else PM_REFINE(8);
+#undef PM_REFINE2
 #undef PM_REFINE
         PM_HIP_CHECK(hipGetLastError());
     }
     return PM_OK;
+}
+
+}  // namespace
+
+extern "C" int pm_bf_knn_l2_f32_dev(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt, int dim,
+                                    int k, int flags, pm_match* dout)
+{
+    PM_REQUIRE(ctx != nullptr, PM_E_INVALID, "ctx is null");
+    PM_REQUIRE(nq >= 0 && nt >= 0 && dim >= 1 && k >= 1 && k <= PM_MAX_K, PM_E_INVALID,
+               "need nq,nt >= 0, dim >= 1, 1 <= k <= PM_MAX_K");
+    PM_REQUIRE(nq == 0 || (dq && dout), PM_E_INVALID, "null query/output pointer");
+    PM_REQUIRE(nt == 0 || dt, PM_E_INVALID, "null train pointer");
+    if (nq == 0) return PM_OK;
+    PM_HIP_CHECK(hipSetDevice(ctx->device));
+    return knn_l2_enqueue(ctx, dq, nq, dt, nt, dim, k, flags, dout, nullptr);
+}
+
+// main.cpp:46 + :49-69 (ratio form) + :77-78 + :89-91 in one call: 2-NN, ratio test, stable compaction and keypoint
+// gather.  On the MFMA routes the last three ride the refinement launch (no separate filter kernel, no launch
+// boundary); otherwise the two entry points it replaces are enqueued one after the other.  Same outputs either way.
+extern "C" int pm_bf_knn_l2_ratio_dev(pm_ctx* ctx, const float* d_q, int nq, const float* d_t, int nt, int dim, int flags,
+                                      float ratio, const float* d_kp1_xy, const float* d_kp2_xy, pm_match* d_knn,
+                                      pm_match* d_good, float* d_xy1, float* d_xy2, int32_t* d_n_good)
+{
+    PM_REQUIRE(ctx != nullptr && d_n_good != nullptr, PM_E_INVALID, "null argument");
+    PM_REQUIRE(nq >= 0 && nt >= 0 && dim >= 1, PM_E_INVALID, "need nq,nt >= 0, dim >= 1");
+    PM_REQUIRE(nq == 0 || (d_q && d_good), PM_E_INVALID, "null query/output pointer");
+    PM_REQUIRE(nt == 0 || d_t, PM_E_INVALID, "null train pointer");
+    PM_REQUIRE((d_kp1_xy == nullptr) == (d_kp2_xy == nullptr), PM_E_INVALID, "give both keypoint arrays or none");
+    PM_REQUIRE(d_kp1_xy == nullptr || (d_xy1 && d_xy2), PM_E_INVALID, "null point outputs");
+    PM_HIP_CHECK(hipSetDevice(ctx->device));
+    if (nq == 0) {
+        PM_HIP_CHECK(hipMemsetAsync(d_n_good, 0, sizeof(int32_t), ctx->stream));
+        return PM_OK;
+    }
+    KnnFuse fz{};
+    fz.ratio = ratio; fz.kp1 = d_kp1_xy; fz.kp2 = d_kp2_xy; fz.good = d_good; fz.xy1 = d_xy1; fz.xy2 = d_xy2; fz.n_out = d_n_good;
+    const bool separate = ctx->opts[PM_OPT_FILTER_FUSION] == 1;      // tests / A-B timing: the two-launch form
+    int rc;
+    if (!separate) {
+        rc = knn_l2_enqueue(ctx, d_q, nq, d_t, nt, dim, 2, flags, d_knn, &fz);
+        if (rc <= 0) return rc;                                      // done (fused) or failed
+        // rc == 1: the exact kernel ran (shape outside the MFMA routes) into d_knn; the filter follows as its own launch
+        return pm_filter_ratio_gather_dev(ctx, d_knn, nq, 2, ratio, d_kp1_xy, d_kp2_xy, d_good, d_xy1, d_xy2, d_n_good);
+    }
+    PM_REQUIRE(d_knn != nullptr, PM_E_INVALID, "PM_OPT_FILTER_FUSION = 1 needs d_knn");
+    rc = knn_l2_enqueue(ctx, d_q, nq, d_t, nt, dim, 2, flags, d_knn, nullptr);
+    if (rc != PM_OK) return rc;
+    return pm_filter_ratio_gather_dev(ctx, d_knn, nq, 2, ratio, d_kp1_xy, d_kp2_xy, d_good, d_xy1, d_xy2, d_n_good);
 }
 
 extern "C" int pm_bf_knn_l2_f32(pm_ctx* ctx, const float* q, int nq, const float* t, int nt, int dim, int k,

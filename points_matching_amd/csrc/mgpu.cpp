@@ -347,11 +347,12 @@ extern "C" int pm_mgpu_match_ransac(pm_mgpu* mg, const void* desc1, int n1, cons
             if (binary)
                 rc = pm_bf_knn_hamming_u8_dev(d.ctx, reinterpret_cast<const uint8_t*>(dq), rows, reinterpret_cast<const uint8_t*>(dt),
                                               n2, dim, 2, dknn);
-            else
-                rc = pm_bf_knn_l2_f32_dev(d.ctx, reinterpret_cast<const float*>(dq), rows, reinterpret_cast<const float*>(dt), n2,
-                                          dim, 2, knn_flags, dknn);
         }
-        if (rc == PM_OK) rc = pm_filter_ratio_gather_dev(d.ctx, dknn, rows, 2, ratio, dkp1, dkp2, dgood, dxy1, dxy2, dcount);
+        if (rc == PM_OK && !binary)
+            rc = pm_bf_knn_l2_ratio_dev(d.ctx, reinterpret_cast<const float*>(dq), rows, reinterpret_cast<const float*>(dt), n2, dim,
+                                        knn_flags, ratio, dkp1, dkp2, dknn, dgood, dxy1, dxy2, dcount);
+        else if (rc == PM_OK)
+            rc = pm_filter_ratio_gather_dev(d.ctx, dknn, rows, 2, ratio, dkp1, dkp2, dgood, dxy1, dxy2, dcount);
         if (rc != PM_OK) { (void)sync_all(mg); return rc; }
     }
     int rc = gather_in_place(mg, gblk, blk_al);                 // exchange 1: the survivor blocks

@@ -164,10 +164,9 @@ extern "C" int pm_batch_run(pm_batch* b, const pm_pair_job* jobs, int n_jobs, fl
         PM_BATCH_HIP(hipMemcpyAsync(L.dt, jb.desc2, sizeof(float) * n2 * b->dim, hipMemcpyHostToDevice, s));
         PM_BATCH_HIP(hipMemcpyAsync(L.dkp1, jb.kp1_xy, sizeof(float) * 2 * n1, hipMemcpyHostToDevice, s));
         PM_BATCH_HIP(hipMemcpyAsync(L.dkp2, jb.kp2_xy, sizeof(float) * 2 * n2, hipMemcpyHostToDevice, s));
-        if (rc == PM_OK) rc = pm_bf_knn_l2_f32_dev(L.ctx, L.dq, jb.n1, L.dt, jb.n2, b->dim, 2, knn_flags, L.dknn);
         if (rc == PM_OK)
-            rc = pm_filter_ratio_gather_dev(L.ctx, L.dknn, jb.n1, 2, ratio, L.dkp1, L.dkp2, L.dgood, L.dxy1, L.dxy2,
-                                            &L.dres->n_good);
+            rc = pm_bf_knn_l2_ratio_dev(L.ctx, L.dq, jb.n1, L.dt, jb.n2, b->dim, knn_flags, ratio, L.dkp1, L.dkp2, L.dknn, L.dgood,
+                                        L.dxy1, L.dxy2, &L.dres->n_good);
         if (rc == PM_OK)
             rc = pm_ransac_run_dev(L.ctx, L.dxy1, L.dxy2, jb.n1, &L.dres->n_good, p, &L.dres->key, L.dres->F, L.dmask,
                                    &L.dres->n_inliers);

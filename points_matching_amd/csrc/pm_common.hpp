@@ -70,6 +70,10 @@ struct pm_ctx {
     // stable compaction: epoch-tagged per-block survivor counts
     unsigned* fg_counts = nullptr;
     unsigned fg_epoch = 0;
+    // compaction fused into the L2 refinement: kf_cap arrival words (8 B) followed by kf_cap epoch-tagged counts (4 B)
+    unsigned long long* kf_tile = nullptr;
+    int kf_cap = 0;
+    unsigned kf_epoch = 0;
     // arrival tickets / counters of the one-launch RANSAC kernels; every launch returns them to zero
     int* sync_words = nullptr;
     int opts[PM_OPT_COUNT_] = {};          // pm_ctx_set_option

@@ -136,3 +136,43 @@ def test_device_midpoint_filter_matches_the_reference_rule(ctx, n, scale):
         assert d_mm.cpu().numpy().tolist() == [lo, hi]
         assert np.array_equal(d_xy1.cpu().numpy()[:k], kp1[good_h["queryIdx"]])
         assert np.array_equal(d_xy2.cpu().numpy()[:k], kp2[good_h["trainIdx"]])
+
+
+# ---- matcher + ratio filter + gather in one call (pm_bf_knn_l2_ratio_dev): the filter rides the refinement launch ----
+@pytest.mark.parametrize("nq,nt,dim,kind", [(8192, 8192, 128, "sift"), (1000, 777, 128, "sift"), (33, 500, 64, "surf"),
+                                            (4, 9, 128, "sift"), (2049, 300, 128, "surf"), (300, 1, 128, "sift"),
+                                            (700, 650, 30, "surf")])
+def test_fused_matcher_filter_equals_the_two_call_form(ctx, oracle, nq, nt, dim, kind):
+    import torch
+    dev = torch.device("cuda", 0)
+    w = synth.pair_workload(nq, nt, dim, seed=nq + nt, planted=0.4, kind=kind)
+    flags = pm.api.PM_KNN_HINT_INTEGER if kind == "sift" else 0
+    d_q, d_t = torch.from_numpy(w["q"]).to(dev), torch.from_numpy(w["t"]).to(dev)
+    d_kp1, d_kp2 = torch.from_numpy(w["kp1"]).to(dev), torch.from_numpy(w["kp2"]).to(dev)
+    want = oracle.filter_ratio(oracle.bf_knn_l2(w["q"], w["t"], 2, nthreads=8), 0.8)
+    for mode, with_knn in ((0, True), (0, False), (1, True)):
+        if dim % 4 and not with_knn:
+            continue                                   # the exact kernel needs the record buffer
+        d_knn = torch.zeros((nq, 2, 4), dtype=torch.int32, device=dev)
+        d_good = torch.full((nq, 4), -7, dtype=torch.int32, device=dev)
+        d_xy1 = torch.full((nq, 2), -1.0, dtype=torch.float32, device=dev)
+        d_xy2 = torch.full((nq, 2), -1.0, dtype=torch.float32, device=dev)
+        d_n = torch.full((1,), -1, dtype=torch.int32, device=dev)
+        ctx.set_option(pm.api.PM_OPT_FILTER_FUSION, mode)
+        try:
+            for _ in range(2):                         # twice: arrival words must be back at zero, epochs move on
+                ctx.bf_knn_l2_ratio_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, flags, 0.8, d_kp1.data_ptr(), d_kp2.data_ptr(),
+                                        d_knn.data_ptr() if with_knn else 0, d_good.data_ptr(), d_xy1.data_ptr(),
+                                        d_xy2.data_ptr(), d_n.data_ptr())
+            ctx.synchronize()
+        finally:
+            ctx.set_option(pm.api.PM_OPT_FILTER_FUSION, 0)
+        n = int(d_n.item())
+        assert n == want.size, (mode, with_knn)
+        got = d_good.cpu().numpy().view(pm.MATCH_DTYPE).reshape(-1)[:n]
+        assert_matches_equal(got, want, "fused good list %s" % ((mode, with_knn),))
+        assert (d_xy1.cpu().numpy()[:n] == w["kp1"][want["queryIdx"]]).all()
+        assert (d_xy2.cpu().numpy()[:n] == w["kp2"][want["trainIdx"]]).all()
+        if with_knn:
+            knn = d_knn.cpu().numpy().view(pm.MATCH_DTYPE).reshape(nq, 2)
+            assert_matches_equal(knn, oracle.bf_knn_l2(w["q"], w["t"], 2, nthreads=8), "records")
