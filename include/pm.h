@@ -85,7 +85,7 @@ enum {
     PM_OPT_SCORE_OPERANDS = 2,  /* hypothesis-per-lane scorer: 1 LDS-staged points, 2 scalar-operand pair records */
     PM_OPT_HAMMING_ROUTE  = 3,  /* 1: integer-VALU scan, 2: matrix-core route with 64-bit refinement keys          */
     PM_OPT_KNN_F16_WAVES  = 4,  /* f16/i8 coarse kernel: 1 = 8 waves x 32 queries, 2 = 4 waves x 64 queries        */
-    PM_OPT_FILTER_FUSION  = 5,  /* pm_bf_knn_l2_ratio_dev: 1 = matcher and filter as two launches                  */
+    PM_OPT_FILTER_FUSION  = 5,  /* pm_bf_knn_l2_ratio_dev: 1 = filter as its own launch, 2 = inside the refinement  */
     PM_OPT_COUNT_         = 8
 };
 int  pm_ctx_set_option(pm_ctx* ctx, int option, int value);
@@ -123,9 +123,10 @@ int pm_bf_knn_l2_f32_dev(pm_ctx* ctx, const float* d_q, int nq, const float* d_t
 
 /* main.cpp:46 + :49-69 (ratio form) + :77-78 + :89-91 in ONE call for batches that stay in HBM: 2-NN, ratio test
  * (d1 < ratio * d2, float multiply, strict), stable compaction in query order and keypoint gather — the outputs of
- * pm_bf_knn_l2_f32_dev(k = 2) followed by pm_filter_ratio_gather_dev, bit for bit.  On the MFMA routes the filter
- * rides the refinement launch (no separate kernel).  d_knn (nq x 2 records) may be NULL on those routes; shapes
- * that take the exact kernel (dim % 4 != 0, dim > 128, unaligned rows) need it. */
+ * pm_bf_knn_l2_f32_dev(k = 2) followed by pm_filter_ratio_gather_dev, bit for bit.  d_knn (nq x 2 records) may be
+ * NULL on the MFMA routes: the filter then rides the refinement launch and no record is written (shapes that take
+ * the exact kernel — dim % 4 != 0, dim > 128, unaligned rows — need the buffer).  With d_knn the filter is its own
+ * launch, which measured faster; PM_OPT_FILTER_FUSION pins either form. */
 int pm_bf_knn_l2_ratio_dev(pm_ctx* ctx, const float* d_q, int nq, const float* d_t, int nt, int dim, int flags,
                            float ratio, const float* d_kp1_xy, const float* d_kp2_xy, pm_match* d_knn,
                            pm_match* d_good, float* d_xy1, float* d_xy2, int32_t* d_n_good);

@@ -366,8 +366,10 @@ constexpr unsigned KF_SPIN_LIMIT = 1u << 22;
 // values are read ONCE into registers, the candidates of all lists are compacted into one per-wave
 // LDS list and evaluated together (8 rows per round), so neither the number of lists nor the way the
 // candidates spread over them adds rounds.  (This kernel is VALU-issue bound: one wave per query.)
+// (amdgpu_num_sgpr: the fused tail's pointers pushed the kernel to 95 SGPRs, and above 80 a CU admits 7 instead of 8
+// of these workgroups — 1792 of the 2048 at C3, i.e. a second round: 10 -> 20 us.  Capped, the kernel stays at 8.)
 template <bool VEC4, int NS, bool FUSE>
-__global__ __launch_bounds__(256) void knn_l2_refine(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void knn_l2_refine(
     const float* __restrict__ Q, const float* __restrict__ T, const float* __restrict__ qnorm,
     const unsigned long long* __restrict__ stats, unsigned epoch, unsigned* __restrict__ diag, int nq, int nt,
     int dim, int k, KnnGeom g16, KnnGeom g32, int route, pm_match* __restrict__ out, KnnFuse fz)
@@ -984,8 +986,8 @@ extern "C" int pm_bf_knn_l2_f32_dev(pm_ctx* ctx, const float* dq, int nq, const 
 }
 
 // main.cpp:46 + :49-69 (ratio form) + :77-78 + :89-91 in one call: 2-NN, ratio test, stable compaction and keypoint
-// gather.  On the MFMA routes the last three ride the refinement launch (no separate filter kernel, no launch
-// boundary); otherwise the two entry points it replaces are enqueued one after the other.  Same outputs either way.
+// gather, as the matcher launches followed by the filter launch, or (no record buffer given, or PM_OPT_FILTER_FUSION
+// = 2) with the last three riding the refinement launch.  Same outputs either way.
 extern "C" int pm_bf_knn_l2_ratio_dev(pm_ctx* ctx, const float* d_q, int nq, const float* d_t, int nt, int dim, int flags,
                                       float ratio, const float* d_kp1_xy, const float* d_kp2_xy, pm_match* d_knn,
                                       pm_match* d_good, float* d_xy1, float* d_xy2, int32_t* d_n_good)
@@ -1003,7 +1005,12 @@ extern "C" int pm_bf_knn_l2_ratio_dev(pm_ctx* ctx, const float* d_q, int nq, con
     }
     KnnFuse fz{};
     fz.ratio = ratio; fz.kp1 = d_kp1_xy; fz.kp2 = d_kp2_xy; fz.good = d_good; fz.xy1 = d_xy1; fz.xy2 = d_xy2; fz.n_out = d_n_good;
-    const bool separate = ctx->opts[PM_OPT_FILTER_FUSION] == 1;      // tests / A-B timing: the two-launch form
+    // Measured at C3 (8192 queries): refinement 10.0 us + filter launch 6.4 us against 19.8 us for the fused launch — the
+    // in-launch hand-off (write-through store, drain, arrival atomic, look-back, dependent loads) costs about what the
+    // launch boundary it replaces costs, and it lengthens every workgroup.  So the two-launch form is the default
+    // whenever the caller provides the record buffer; PM_OPT_FILTER_FUSION = 2 selects the fused launch, 1 the two launches.
+    const int fusion = ctx->opts[PM_OPT_FILTER_FUSION];
+    const bool separate = fusion == 1 || (fusion == 0 && d_knn != nullptr);
     int rc;
     if (!separate) {
         rc = knn_l2_enqueue(ctx, d_q, nq, d_t, nt, dim, 2, flags, d_knn, &fz);
@@ -1011,7 +1018,7 @@ extern "C" int pm_bf_knn_l2_ratio_dev(pm_ctx* ctx, const float* d_q, int nq, con
         // rc == 1: the exact kernel ran (shape outside the MFMA routes) into d_knn; the filter follows as its own launch
         return pm_filter_ratio_gather_dev(ctx, d_knn, nq, 2, ratio, d_kp1_xy, d_kp2_xy, d_good, d_xy1, d_xy2, d_n_good);
     }
-    PM_REQUIRE(d_knn != nullptr, PM_E_INVALID, "PM_OPT_FILTER_FUSION = 1 needs d_knn");
+    PM_REQUIRE(d_knn != nullptr, PM_E_INVALID, "the two-launch form needs d_knn");
     rc = knn_l2_enqueue(ctx, d_q, nq, d_t, nt, dim, 2, flags, d_knn, nullptr);
     if (rc != PM_OK) return rc;
     return pm_filter_ratio_gather_dev(ctx, d_knn, nq, 2, ratio, d_kp1_xy, d_kp2_xy, d_good, d_xy1, d_xy2, d_n_good);

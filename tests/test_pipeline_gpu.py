@@ -150,7 +150,7 @@ def test_fused_matcher_filter_equals_the_two_call_form(ctx, oracle, nq, nt, dim,
     d_q, d_t = torch.from_numpy(w["q"]).to(dev), torch.from_numpy(w["t"]).to(dev)
     d_kp1, d_kp2 = torch.from_numpy(w["kp1"]).to(dev), torch.from_numpy(w["kp2"]).to(dev)
     want = oracle.filter_ratio(oracle.bf_knn_l2(w["q"], w["t"], 2, nthreads=8), 0.8)
-    for mode, with_knn in ((0, True), (0, False), (1, True)):
+    for mode, with_knn in ((0, True), (0, False), (1, True), (2, True)):
         if dim % 4 and not with_knn:
             continue                                   # the exact kernel needs the record buffer
         d_knn = torch.zeros((nq, 2, 4), dtype=torch.int32, device=dev)
