@@ -182,17 +182,29 @@ __global__ __launch_bounds__(256) void knn_l2_prep16(const float* __restrict__ Q
     _Float16* xh = is_t ? Th : Qh;
     const int row0 = (is_t ? blockIdx.x - qblocks : blockIdx.x) * 64;
     unsigned mx = 0u, bad = 0u;
+    // all eight 16-byte loads of a thread's four rows are requested before anything is computed (unconditional, clamped
+    // addresses: a guarded load makes hipcc wait for each in turn — four dependent memory round trips instead of one)
+    const int c0 = 8 * sub;
+    f32x4 ld[4][2];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = row0 + it * 16 + grp;
+        const float* p = x + static_cast<size_t>(row < n ? row : n - 1) * dim;       // n >= 1 on this route
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int c = c0 + 4 * e < dim ? c0 + 4 * e : dim - 4;                      // dim % 4 == 0, dim >= 4
+            ld[it][e] = *reinterpret_cast<const f32x4*>(p + c);
+        }
+    }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int row = row0 + it * 16 + grp;                 // < n_pad by construction
         const bool live = row < n;
-        const float* p = x + static_cast<size_t>(live ? row : 0) * dim;
-        const int c0 = 8 * sub;
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; e += 4) {
-            f32x4 u = {0.f, 0.f, 0.f, 0.f};
-            if (live && c0 + e < dim) u = *reinterpret_cast<const f32x4*>(p + c0 + e);   // dim % 4 == 0
+            f32x4 u = ld[it][e >> 2];
+            if (!(live && c0 + e < dim)) u = f32x4{0.f, 0.f, 0.f, 0.f};
             v[e] = u[0]; v[e + 1] = u[1]; v[e + 2] = u[2]; v[e + 3] = u[3];
         }
         float s = 0.f;

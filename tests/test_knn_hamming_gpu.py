@@ -141,3 +141,14 @@ def test_hamming_randomised_shapes(ctx, oracle):
             q[:sel.size, rng.integers(0, nbytes)] ^= np.uint8(rng.integers(0, 256))
         assert_matches_equal(ctx.bf_knn_hamming(q, t, k), oracle.bf_knn_hamming(q, t, k),
                              "case %d: nq=%d nt=%d bytes=%d k=%d" % (case, nq, nt, nbytes, k))
+
+
+def test_hamming_lds_dma_staging_same_result(ctx, oracle):
+    q, t, _ = synth.orb_like(3000, 5000, 32, seed=99)
+    base = ctx.bf_knn_hamming(q, t, 2)
+    ctx.set_option(pm.api.PM_OPT_KNN_STAGING, 1)
+    try:
+        assert_matches_equal(ctx.bf_knn_hamming(q, t, 2), base, "register staging vs LDS-DMA (default)")
+    finally:
+        ctx.set_option(pm.api.PM_OPT_KNN_STAGING, 0)
+    assert_matches_equal(base, oracle.bf_knn_hamming(q, t, 2, nthreads=8), "vs oracle")

@@ -222,3 +222,22 @@ def test_knn_32k_long_sweeps_slice_and_no_list_overflow(ctx, oracle, kind):
     assert st["rescans"] <= 2 and st["nonfinite"] == 0, st
     planted = truth >= 0
     assert (got["trainIdx"][planted, 0] == truth[planted]).mean() > 0.99
+
+
+@pytest.mark.parametrize("nq,nt", [(700, 1000), (8192, 8192), (300, 20000)])
+def test_lds_dma_staging_same_result(ctx, oracle, nq, nt):
+    """PM_OPT_KNN_STAGING: the train tiles of the f16 coarse kernel go global -> LDS by LDS-DMA (2, the default: padded
+    rows through the per-lane source address) or through registers (1); same candidates, same result."""
+    w = synth.pair_workload(nq, nt, 128, seed=nq ^ nt, planted=0.4, kind="sift")
+    base = ctx.bf_knn_l2(w["q"], w["t"], 2, pm.api.PM_KNN_HINT_INTEGER)
+    try:
+        for staging in (1, 2):
+            ctx.set_option(pm.api.PM_OPT_KNN_STAGING, staging)
+            for waves in (0, 1, 2):
+                ctx.set_option(pm.api.PM_OPT_KNN_F16_WAVES, waves)
+                assert_matches_equal(ctx.bf_knn_l2(w["q"], w["t"], 2, pm.api.PM_KNN_HINT_INTEGER), base,
+                                     "staging %d, waves %d" % (staging, waves))
+    finally:
+        ctx.set_option(pm.api.PM_OPT_KNN_STAGING, 0)
+        ctx.set_option(pm.api.PM_OPT_KNN_F16_WAVES, 0)
+    assert_matches_equal(base[:128], oracle.bf_knn_l2(w["q"][:128], w["t"], 2, nthreads=8), "vs oracle")
