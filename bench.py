@@ -197,6 +197,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="debugging: gloo lets a multi-rank run share ONE GPU (with --single-device); the driver uses nccl")
     ap.add_argument("--single-device", action="store_true", help="debugging: every rank uses cuda:0")
+    ap.add_argument("--ransac-path", type=int, default=0, choices=[0, 1, 2],
+                    help="A/B timing: PM_OPT_RANSAC_PATH (0 automatic, 1 solve + score launches, 2 one-launch kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
@@ -270,6 +272,7 @@ def main():
         nq_total = nq * world
 
     ctx = pm.Context(local_rank)
+    ctx.set_option(pm.api.PM_OPT_RANSAC_PATH, args.ransac_path)
     stream = torch.cuda.Stream(device=dev)      # a real (non-null) stream shared by torch and the library
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)

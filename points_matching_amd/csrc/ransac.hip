@@ -519,9 +519,17 @@ int run_local(pm_ctx* ctx, const float* dxy1, const float* dxy2, int n, const in
     return score_shard(ctx, dxy1, dxy2, n, d_n, p, d_key, sc, &ft);
 }
 
-// One-launch kernel (ransac_fused.hip, the default) or the hypothesis-per-lane solve + score launches below
-// (PM_OPT_RANSAC_PATH = 1: kept for A/B timing and as an independent second implementation in the tests).
-bool use_fused(const pm_ctx* ctx, long long /*n_cap*/) { return ctx->opts[PM_OPT_RANSAC_PATH] != 1; }
+// One-launch kernel (ransac_fused.hip) or the hypothesis-per-lane solve + score launches below?  The one-launch kernel
+// wins wherever launches, atomics and tickets dominate (C3: 10k ids x 2.3k matches, C5: 2k x 1.1k); for very large
+// runs the lane-per-hypothesis scorer with scalar-operand points is ahead (C4, 100k ids x 9.2k matches on one GPU:
+// 346 us against 370 us), so those keep it.  The rule uses the capacity (the count may live on the device).
+// PM_OPT_RANSAC_PATH pins either (tests run both: two independent implementations of the same spec).
+bool use_fused(const pm_ctx* ctx, long long n_cap, long long nh)
+{
+    const int opt = ctx->opts[PM_OPT_RANSAC_PATH];
+    if (opt) return opt == 2;
+    return n_cap * nh < (1LL << 30);
+}
 
 // Shared host-pointer driver: run the shard (hyp < 0) or take the given hypothesis, then finalise.
 int host_run(pm_ctx* ctx, const float* xy1, const float* xy2, int n, const pm_ransac_params* p, int64_t hyp,
@@ -540,7 +548,7 @@ int host_run(pm_ctx* ctx, const float* xy1, const float* xy2, int n, const pm_ra
     PM_HIP_CHECK(hipSetDevice(ctx->device));
 
     const size_t xyb = sizeof(float) * 2 * static_cast<size_t>(n);
-    const bool fused = hyp < 0 && p->hyp_end > p->hyp_begin && use_fused(ctx, n);
+    const bool fused = hyp < 0 && p->hyp_end > p->hyp_begin && use_fused(ctx, n, p->hyp_end - p->hyp_begin);
     const size_t need = 2 * pm::align_up(xyb, 256) + pm::align_up(static_cast<size_t>(n), 256) + 512 +
                         (fused ? fused_scratch_bytes(ctx, p) : shard_scratch_bytes(p, n)) + 2048;
     rc = pm::arena_reserve(ctx, need);
@@ -664,7 +672,7 @@ extern "C" int pm_ransac_run_dev(pm_ctx* ctx, const float* d_xy1, const float* d
 {
     PM_REQUIRE(d_best_key && d_F && d_mask && d_n_inliers, PM_E_INVALID, "null argument");
     unsigned long long* key = reinterpret_cast<unsigned long long*>(d_best_key);
-    if (ctx && p && n_max >= 1 && d_xy1 && d_xy2 && use_fused(ctx, n_max)) {
+    if (ctx && p && n_max >= 1 && d_xy1 && d_xy2 && use_fused(ctx, n_max, p->hyp_end - p->hyp_begin)) {
         int rc = check_params(p);
         if (rc != PM_OK) return rc;
         PM_REQUIRE(p->hyp_end > p->hyp_begin, PM_E_INVALID, "empty hypothesis range");

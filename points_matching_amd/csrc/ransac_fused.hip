@@ -26,8 +26,9 @@ namespace {
 
 constexpr int RF_THREADS = 256;
 constexpr int RF_PTS_PER_SLOT = 2 * RF_THREADS;      // points covered by one register slot (pair) of every thread
-constexpr int RF_PPT2 = 5;                           // register slots per thread: tiles of 2560 correspondences
-static_assert(RF_PPT2 <= 5, "score_tile is instantiated for 1..5 slots");
+constexpr int RF_PPT2 = 5;                           // register slots per thread: tiles of 2560 correspondences (config C3)
+constexpr int RF_PPT2_BIG = 10;                      // ... of 5120 for capacities beyond one small tile
+static_assert(RF_PPT2_BIG <= 10, "score_tile is instantiated for 1..10 slots");
 
 struct RfSlot {                   // one per workgroup, 128 B apart (never shares a line with another writer)
     unsigned long long key;
@@ -191,7 +192,10 @@ __device__ __forceinline__ void score_tile(const float (*__restrict__ mdl)[12], 
         int c = 0;
 #pragma unroll
         for (int k = 0; k < KM; ++k) c += __popcll(va[k]) + __popcll(vb[k]);
-        if (lane == 0) cnt[wave][s] = first ? c : cnt[wave][s] + c;
+        if (lane == 0) {
+            if (first) cnt[wave][s] = c;
+            else __hip_atomic_fetch_add(&cnt[wave][s], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add, no return: no wait
+        }
     }
 }
 
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(RF_THREADS) void ransac_fused(pm_points_view v, uin
         if (t > 0) kmax = load_tile(t);
         switch (kmax) {                                      // workgroup-uniform
 #define PM_CASE(KM_) case KM_: score_tile<KIND, PPT2, (KM_ <= PPT2 ? KM_ : PPT2)>(s_mdl, s_cnt, hcount, X, Y, XP, YP, thr2, t == 0, lane, wave); break;
-            PM_CASE(1) PM_CASE(2) PM_CASE(3) PM_CASE(4) PM_CASE(5)
+            PM_CASE(1) PM_CASE(2) PM_CASE(3) PM_CASE(4) PM_CASE(5) PM_CASE(6) PM_CASE(7) PM_CASE(8) PM_CASE(9) PM_CASE(10)
 #undef PM_CASE
             default:
                 for (int s = lane; s < hcount; s += 64) s_cnt[wave][s] = t == 0 ? 0 : s_cnt[wave][s];   // empty tile (n == 0)
@@ -557,9 +561,16 @@ int fused_launch(pm_ctx* ctx, const pm_points_view& v, const pm_ransac_params* p
 #define PM_RF(KIND_, PPT2_)                                                                                              \
     hipLaunchKernelGGL((ransac_fused<KIND_, PPT2_>), dim3(nwg), dim3(RF_THREADS), 0, ctx->stream, v, p->seed, p->hyp_begin, \
                        static_cast<int>(nh), hb, thr2, slots, sync, out)
-    const bool small = cap_total <= 2 * RF_PTS_PER_SLOT;
-    if (p->error_kind == PM_ERR_SAMPSON) { if (small) PM_RF(PM_ERR_SAMPSON, 2); else PM_RF(PM_ERR_SAMPSON, RF_PPT2); }
-    else { if (small) PM_RF(PM_ERR_SYM_EPIPOLAR, 2); else PM_RF(PM_ERR_SYM_EPIPOLAR, RF_PPT2); }
+    const int depth = cap_total <= 2 * RF_PTS_PER_SLOT ? 2 : (cap_total <= RF_PPT2 * RF_PTS_PER_SLOT ? RF_PPT2 : RF_PPT2_BIG);
+#define PM_RF_K(KIND_)                                                                   \
+    do {                                                                                 \
+        if (depth == 2) PM_RF(KIND_, 2);                                                 \
+        else if (depth == RF_PPT2) PM_RF(KIND_, RF_PPT2);                                \
+        else PM_RF(KIND_, RF_PPT2_BIG);                                                  \
+    } while (0)
+    if (p->error_kind == PM_ERR_SAMPSON) PM_RF_K(PM_ERR_SAMPSON);
+    else PM_RF_K(PM_ERR_SYM_EPIPOLAR);
+#undef PM_RF_K
 #undef PM_RF
     PM_HIP_CHECK(hipGetLastError());
     return PM_OK;
