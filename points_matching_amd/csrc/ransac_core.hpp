@@ -9,6 +9,10 @@
 
 namespace pm_ransac {
 
+#ifndef PM_SOLVE_STAMP
+#define PM_SOLVE_STAMP(i) do { } while (0)       // diagnostic builds of ransac_fused.hip time the solver's phases
+#endif
+
 constexpr int MODEL_STRIDE = 12;   // 9 x fp32 F, valid flag, 2 pad
 
 __device__ __forceinline__ uint64_t mix64(uint64_t z)
@@ -18,20 +22,48 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z)
     return z ^ (z >> 31);
 }
 
-// SPEC S6: 8 distinct indices in [0, n) as a pure function of (seed, h, n).
+// SPEC S6: 8 distinct indices in [0, n) as a pure function of (seed, h, n): draws d = 0, 1, ... give candidates
+// c_d = floor(n * hi32(mix64(stream + (d+1)*phi)) / 2^32); a candidate equal to an earlier one is skipped; after 64
+// draws the smallest unused integers complete the sample.  Same results as the sequential loop of the oracle, computed
+// so that the 64-bit multiplies of the first eight draws are independent (they dominated: 5.3k of the solver's 24k
+// cycles with the draw-by-draw loop) and the common case — eight distinct candidates — touches no select chains.
 __device__ __forceinline__ void sample8(uint64_t seed, uint64_t h, int n, int (&idx)[8])
 {
     const uint64_t stream = mix64(seed ^ 0x9E3779B97F4A7C15ULL) ^ mix64(h + 0xD1B54A32D192ED03ULL);
+    int cand[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        const uint64_t r = mix64(stream + static_cast<uint64_t>(d + 1) * 0x9E3779B97F4A7C15ULL);
+        cand[d] = static_cast<int>(((r >> 32) * static_cast<uint64_t>(static_cast<uint32_t>(n))) >> 32);
+    }
+    unsigned dup = 0u;                         // bit d: candidate d repeats an earlier one (so it is skipped)
+#pragma unroll
+    for (int d = 1; d < 8; ++d)
+#pragma unroll
+        for (int e = 0; e < d; ++e) dup |= (cand[e] == cand[d] ? 1u : 0u) << d;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) idx[s] = cand[s];
+    if (dup == 0u) return;
+    // rare: keep the first occurrences in draw order, then go on drawing
 #pragma unroll
     for (int s = 0; s < 8; ++s) idx[s] = -1;
     int cnt = 0;
-    for (uint64_t d = 0; d < 64 && cnt < 8; ++d) {
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        if (!((dup >> d) & 1u)) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                if (s == cnt) idx[s] = cand[d];
+            ++cnt;
+        }
+    }
+    for (uint64_t d = 8; d < 64 && cnt < 8; ++d) {
         const uint64_t r = mix64(stream + (d + 1) * 0x9E3779B97F4A7C15ULL);
         const int c = static_cast<int>(((r >> 32) * static_cast<uint64_t>(static_cast<uint32_t>(n))) >> 32);
-        bool dup = false;
+        bool rep = false;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) dup |= (s < cnt) && (idx[s] == c);
-        if (!dup) {
+        for (int s = 0; s < 8; ++s) rep |= (s < cnt) && (idx[s] == c);
+        if (!rep) {
 #pragma unroll
             for (int s = 0; s < 8; ++s)
                 if (s == cnt) idx[s] = c;
@@ -39,10 +71,10 @@ __device__ __forceinline__ void sample8(uint64_t seed, uint64_t h, int n, int (&
         }
     }
     for (int c = 0; cnt < 8; ++c) {
-        bool dup = false;
+        bool rep = false;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) dup |= (s < cnt) && (idx[s] == c);
-        if (!dup) {
+        for (int s = 0; s < 8; ++s) rep |= (s < cnt) && (idx[s] == c);
+        if (!rep) {
 #pragma unroll
             for (int s = 0; s < 8; ++s)
                 if (s == cnt) idx[s] = c;
@@ -110,6 +142,7 @@ __device__ __forceinline__ bool solve8(const double (&x1)[8], const double (&y1)
     if (!hartley8(x1, y1, ax, ay, s1, t1x, t1y)) return false;
     if (!hartley8(x2, y2, bx, by, s2, t2x, t2y)) return false;
 
+    PM_SOLVE_STAMP(1);
     // B = A^T (9 x 8): column c is the epipolar constraint row of correspondence c
     double B[9][8], beta[8];
 #pragma unroll
@@ -142,6 +175,7 @@ __device__ __forceinline__ bool solve8(const double (&x1)[8], const double (&y1)
             for (int i = j + 1; i < 9; ++i) B[i][c] = fma(-w, B[i][j], B[i][c]);
         }
     }
+    PM_SOLVE_STAMP(2);
     // null vector f = H0 H1 ... H7 e8
     double f[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0};
 #pragma unroll
@@ -155,6 +189,7 @@ __device__ __forceinline__ bool solve8(const double (&x1)[8], const double (&y1)
 #pragma unroll
         for (int i = j + 1; i < 9; ++i) f[i] = fma(-w, B[i][j], f[i]);
     }
+    PM_SOLVE_STAMP(3);
     // rank 2: one-sided Jacobi on the columns of G, six fixed sweeps, then drop the smallest column
     double G[3][3], V[3][3] = {{1.0, 0.0, 0.0}, {0.0, 1.0, 0.0}, {0.0, 0.0, 1.0}};
 #pragma unroll
@@ -166,6 +201,7 @@ __device__ __forceinline__ bool solve8(const double (&x1)[8], const double (&y1)
         jacobi_pair<0, 2>(G, V);
         jacobi_pair<1, 2>(G, V);
     }
+    PM_SOLVE_STAMP(4);
     double cn[3];
 #pragma unroll
     for (int p = 0; p < 3; ++p) {

@@ -18,6 +18,14 @@
 //     multi-GPU run exchanges (sharded run: one all-gather, then pm_ransac_finish_parts_dev on every rank).
 // The correspondences may be given as `parts` padded blocks with device-side counts (the all-gathered survivors
 // of a query-row-sharded matcher): the view is resolved while loading, no concatenation pass exists.
+#ifdef PM_RF_STAMPS
+#include <hip/hip_runtime.h>
+__device__ unsigned long long g_rf_solve_stamps[4096 * 8];
+#define PM_SOLVE_STAMP(i)                                                                                       \
+    do {                                                                                                        \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) g_rf_solve_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#endif
 #include "ransac_core.hpp"
 #include "ransac_internal.hpp"
 
@@ -96,7 +104,9 @@ __device__ __forceinline__ bool hyp_model_view(const pm_points_view& v, const in
                                                uint64_t h, double (&F)[9])
 {
     int idx[8];
+    PM_SOLVE_STAMP(5);
     sample8(seed, h, n, idx);
+    PM_SOLVE_STAMP(6);
     double x1[8], y1[8], x2[8], y2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -105,7 +115,10 @@ __device__ __forceinline__ bool hyp_model_view(const pm_points_view& v, const in
         x1[i] = static_cast<double>(a.x); y1[i] = static_cast<double>(a.y);
         x2[i] = static_cast<double>(b.x); y2[i] = static_cast<double>(b.y);
     }
-    return solve8(x1, y1, x2, y2, F);
+    PM_SOLVE_STAMP(0);
+    const bool ok = solve8(x1, y1, x2, y2, F);
+    PM_SOLVE_STAMP(7);
+    return ok;
 }
 
 // v_pk_fma_f32 with a coefficient broadcast out of a register PAIR by the instruction's op_sel bits (bit i of op_sel /
@@ -584,6 +597,11 @@ using namespace pm_ransac;
 extern "C" int pm_debug_rf_stamps(unsigned long long* out, int n_words)
 {
     PM_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rf_stamps), sizeof(unsigned long long) * n_words, 0, hipMemcpyDeviceToHost));
+    return PM_OK;
+}
+extern "C" int pm_debug_rf_solve_stamps(unsigned long long* out, int n_words)
+{
+    PM_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rf_solve_stamps), sizeof(unsigned long long) * n_words, 0, hipMemcpyDeviceToHost));
     return PM_OK;
 }
 #endif

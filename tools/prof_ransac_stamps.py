@@ -61,3 +61,15 @@ if hasattr(lib, "pm_debug_rf_stamps"):
     print("in-kernel clock: %.2f GHz (median over workgroups; s_memrealtime = 100 MHz)" % float(np.median(cyc[okc] / rt[okc] * 0.1)))
 else:
     print("library has no stamps (build with tools/build_stamps.sh and set PM_LIB_PATH)")
+
+if hasattr(lib, "pm_debug_rf_solve_stamps"):
+    b2 = np.zeros(4096 * 8, np.uint64)
+    lib.pm_debug_rf_solve_stamps(b2.ctypes.data_as(C.c_void_p), b2.size)
+    t = b2.reshape(4096, 8).astype(np.int64)
+    t = t[t[:, 5] != 0]
+    order = [("sample8", 5, 6), ("load 8 points", 6, 0), ("hartley x2", 0, 1), ("QR 9x8", 1, 2), ("null vector", 2, 3),
+             ("jacobi (6 sweeps)", 3, 4), ("rank-2 + denormalise", 4, 7)]
+    print("solver phases of thread 0 (cycles, median over workgroups):")
+    for nm, a, b in order:
+        d = t[:, b] - t[:, a]
+        print("  %-22s %7d" % (nm, np.median(d)))
