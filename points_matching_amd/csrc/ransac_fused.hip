@@ -4,9 +4,10 @@
 // BASELINE.json names (docs/SPEC.md S6-S9).
 //
 // Mapping (MI355X-first: the correspondences are scored out of registers):
-//   * a workgroup (4 waves) owns `hb` consecutive hypothesis ids and ALL correspondences: lane = correspondence
-//     pair (two points per packed-f32 instruction), 2*PPT2 points per thread = a tile of 2560 correspondences
-//     (config C3: one tile, loaded once); longer sets are walked tile by tile, every tile against all hb models;
+//   * a workgroup owns `hb` consecutive hypothesis ids and ALL correspondences.  It is two TEAMS of four waves (one
+//     wave per SIMD each); every team holds the whole tile — lane = correspondence pair (two points per packed-f32
+//     instruction), 2*PPT2 points per thread = 2560 or 5120 correspondences (config C3: one tile, loaded once; longer
+//     sets are walked tile by tile) — and scores every second hypothesis;
 //   * solve phase: lane s < hb samples and solves hypothesis s (fp64, SPEC S7) and leaves the f32 model in LDS;
 //   * score phase: the model of hypothesis s is a wave-wide LDS broadcast, every lane tests its own points
 //     (v_pk_fma_f32), the verdicts leave the VALU as a v_cmp mask and are counted on the SCALAR unit
@@ -32,8 +33,10 @@ __device__ unsigned long long g_rf_solve_stamps[4096 * 8];
 namespace pm_ransac {
 namespace {
 
-constexpr int RF_THREADS = 256;
-constexpr int RF_PTS_PER_SLOT = 2 * RF_THREADS;      // points covered by one register slot (pair) of every thread
+constexpr int RF_THREADS = 256;                      // a TEAM: four waves, one per SIMD, holding one tile of correspondences
+constexpr int RF_TEAMS = 2;                          // teams per workgroup: team t scores the hypotheses s = t (mod 2)
+constexpr int RF_WG = RF_THREADS * RF_TEAMS;         // 512 threads: two waves per SIMD, all in step (one barrier domain)
+constexpr int RF_PTS_PER_SLOT = 2 * RF_THREADS;      // points covered by one register slot (pair) of every thread of a team
 constexpr int RF_PPT2 = 5;                           // register slots per thread: tiles of 2560 correspondences (config C3)
 constexpr int RF_PPT2_BIG = 10;                      // ... of 5120 for capacities beyond one small tile
 static_assert(RF_PPT2_BIG <= 10, "score_tile is instantiated for 1..10 slots");
@@ -121,45 +124,61 @@ __device__ __forceinline__ bool hyp_model_view(const pm_points_view& v, const in
     return ok;
 }
 
-// v_pk_fma_f32 with a coefficient broadcast out of a register PAIR by the instruction's op_sel bits (bit i of op_sel /
-// op_sel_hi picks the low or high dword of source i for the low / high result lane): d = splat(ap[A]) * b + splat(cp[C])
-// resp. + c.  hipcc knows the encoding (it emits it for a lone splat) but hoists the splats of a model into 21 v_mov
-// per hypothesis once they are used by several point slots; the asm keeps them free.  One IEEE fma per component,
-// like __builtin_elementwise_fma.
+// The model of a hypothesis is wave-uniform, so its coefficients ride in SGPR pairs and reach v_pk_fma_f32 through the
+// instruction's op_sel bits (bit i of op_sel / op_sel_hi picks the low or high dword of source i for the low / high
+// result lane): no register splats (hipcc hoists 21 v_mov per hypothesis otherwise) and 80 fewer VGPRs than holding the
+// model in vector registers.  gfx950 allows one scalar register (pair) per VALU instruction, so the pairs are laid out
+// such that the two coefficients of every inner operation share a pair.  (Measured: the score phase runs at ~6 cycles
+// per VALU instruction per SIMD with two OR four waves per SIMD, with VGPR or SGPR coefficients alike — the packed-f32
+// pipe, not occupancy or operand fetch, bounds it; unpacked v_fma_f32 took 1.5x longer.)
+//   sfma_in (q, A, y, C)   : splat(q[A]) * y + splat(q[C])
+//   sfma_out(q, A, x, acc) : splat(q[A]) * x + acc
+// One IEEE fma per component, exactly like __builtin_elementwise_fma on the same values.
 template <int A, int C>
-__device__ __forceinline__ f32x2 pk_fma_ss(f32x2 ap, f32x2 b, f32x2 cp)
+__device__ __forceinline__ f32x2 sfma_in(unsigned long long q, f32x2 y)
 {
     f32x2 d;
-    if (A == 0 && C == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(d) : "v"(ap), "v"(b), "v"(cp));
-    if (A == 0 && C == 1) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,1,1]" : "=v"(d) : "v"(ap), "v"(b), "v"(cp));
-    if (A == 1 && C == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(d) : "v"(ap), "v"(b), "v"(cp));
-    if (A == 1 && C == 1) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(ap), "v"(b), "v"(cp));
+    if (A == 0 && C == 1) asm("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[0,0,1] op_sel_hi:[0,1,1]" : "=v"(d) : "s"(q), "v"(y));
+    if (A == 1 && C == 0) asm("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(d) : "s"(q), "v"(y));
     return d;
 }
 template <int A>
-__device__ __forceinline__ f32x2 pk_fma_sv(f32x2 ap, f32x2 b, f32x2 c)
+__device__ __forceinline__ f32x2 sfma_out(unsigned long long q, f32x2 x, f32x2 acc)
 {
     f32x2 d;
-    if (A == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(d) : "v"(ap), "v"(b), "v"(c));
-    if (A == 1) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(ap), "v"(b), "v"(c));
+    if (A == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(d) : "s"(q), "v"(x), "v"(acc));
+    if (A == 1) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "s"(q), "v"(x), "v"(acc));
     return d;
 }
 
-// SPEC S8 on two correspondences (the packed form of inlier32, same operations bit for bit) with the model held as
-// the register pairs an LDS broadcast read delivers: p0 = (f0, f1), p1 = (f2, f3), p2 = (f4, f5), p3 = (f6, f7),
-// p4 = (f8, valid).
-template <int KIND>
-__device__ __forceinline__ void inlier_pk_model(f32x4v m0, f32x4v m1, f32x2 p4, f32x2 x, f32x2 y, f32x2 xp, f32x2 yp, float thr2,
-                                                bool& ia, bool& ib)
+// the six scalar pairs of a model: (f1,f2) (f4,f5) (f7,f8) (f3,f6) (f4,f7) (f0,f3)
+struct ModelS {
+    unsigned long long q12, q45, q78, q36, q47, q03;
+};
+__device__ __forceinline__ unsigned long long spair(float lo, float hi)
 {
-    const f32x2 p0 = __builtin_shufflevector(m0, m0, 0, 1), p1 = __builtin_shufflevector(m0, m0, 2, 3);
-    const f32x2 p2 = __builtin_shufflevector(m1, m1, 0, 1), p3 = __builtin_shufflevector(m1, m1, 2, 3);
-    const f32x2 a = pk_fma_sv<0>(p0, x, pk_fma_ss<1, 0>(p0, y, p1));       // f0*x + (f1*y + f2)
-    const f32x2 b = pk_fma_sv<1>(p1, x, pk_fma_ss<0, 1>(p2, y, p2));       // f3*x + (f4*y + f5)
-    const f32x2 c = pk_fma_sv<0>(p3, x, pk_fma_ss<1, 0>(p3, y, p4));       // f6*x + (f7*y + f8)
+    const unsigned l = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(__float_as_uint(lo))));
+    const unsigned h = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(__float_as_uint(hi))));
+    return (static_cast<unsigned long long>(h) << 32) | l;
+}
+__device__ __forceinline__ ModelS model_to_sgprs(f32x4v m0, f32x4v m1, f32x2 m2)
+{
+    ModelS s;
+    s.q12 = spair(m0[1], m0[2]); s.q45 = spair(m1[0], m1[1]); s.q78 = spair(m1[3], m2[0]);
+    s.q36 = spair(m0[3], m1[2]); s.q47 = spair(m1[0], m1[3]); s.q03 = spair(m0[0], m0[3]);
+    return s;
+}
+
+// SPEC S8 on two correspondences (the packed form of inlier32, same operations bit for bit).
+template <int KIND>
+__device__ __forceinline__ void inlier_pk_model(const ModelS& m, f32x2 x, f32x2 y, f32x2 xp, f32x2 yp, float thr2, bool& ia, bool& ib)
+{
+    const f32x2 a = sfma_out<0>(m.q03, x, sfma_in<0, 1>(m.q12, y));        // f0*x + (f1*y + f2)
+    const f32x2 b = sfma_out<1>(m.q03, x, sfma_in<0, 1>(m.q45, y));        // f3*x + (f4*y + f5)
+    const f32x2 c = sfma_out<1>(m.q36, x, sfma_in<0, 1>(m.q78, y));        // f6*x + (f7*y + f8)
     const f32x2 num = __builtin_elementwise_fma(xp, a, __builtin_elementwise_fma(yp, b, c));
-    const f32x2 at = pk_fma_sv<0>(p0, xp, pk_fma_ss<1, 0>(p1, yp, p3));    // f0*x' + (f3*y' + f6)
-    const f32x2 bt = pk_fma_sv<1>(p0, xp, pk_fma_ss<0, 1>(p2, yp, p3));    // f1*x' + (f4*y' + f7)
+    const f32x2 at = sfma_out<0>(m.q03, xp, sfma_in<0, 1>(m.q36, yp));     // f0*x' + (f3*y' + f6)
+    const f32x2 bt = sfma_out<0>(m.q12, xp, sfma_in<0, 1>(m.q47, yp));     // f1*x' + (f4*y' + f7)
     const f32x2 n2 = num * num;
     const f32x2 t2 = f32x2{thr2, thr2};
     if (KIND == PM_ERR_SAMPSON) {
@@ -175,30 +194,40 @@ __device__ __forceinline__ void inlier_pk_model(f32x4v m0, f32x4v m1, f32x2 p4, 
     }
 }
 
-// One tile against all `hcount` models of the workgroup, KM register slots in use (compile-time: no per-slot
+// One tile against this team's share of the `hcount` models of the workgroup, KM register slots in use (compile-time: no per-slot
 // branches).  The model of hypothesis s+1 is requested from LDS before hypothesis s is scored; the ten verdict masks
 // of a hypothesis are collected first and counted afterwards, so the scalar unit waits for the vector pipe once per
 // hypothesis, not once per v_cmp.
 template <int KIND, int PPT2, int KM>
 __device__ __forceinline__ void score_tile(const float (*__restrict__ mdl)[12], int (*__restrict__ cnt)[RF_HB_MAX], int hcount,
                                            const f32x2 (&X)[PPT2], const f32x2 (&Y)[PPT2], const f32x2 (&XP)[PPT2],
-                                           const f32x2 (&YP)[PPT2], float thr2, bool first, int lane, int wave)
+                                           const f32x2 (&YP)[PPT2], float thr2, bool first, int lane, int wave, int team)
 {
-    f32x4v m0 = *reinterpret_cast<const f32x4v*>(&mdl[0][0]);
-    f32x4v m1 = *reinterpret_cast<const f32x4v*>(&mdl[0][4]);
-    f32x2 m2 = *reinterpret_cast<const f32x2*>(&mdl[0][8]);
-    for (int s = 0; s < hcount; ++s) {
+    if (team >= hcount) return;
+    f32x4v m0 = *reinterpret_cast<const f32x4v*>(&mdl[team][0]);
+    f32x4v m1 = *reinterpret_cast<const f32x4v*>(&mdl[team][4]);
+    f32x2 m2 = *reinterpret_cast<const f32x2*>(&mdl[team][8]);
+    for (int s = team; s < hcount; s += RF_TEAMS) {
         const f32x4v c0 = m0, c1 = m1;
         const f32x2 c2 = m2;
-        const int sn = s + 1 < hcount ? s + 1 : s;
+        const int sn = s + RF_TEAMS < hcount ? s + RF_TEAMS : s;
         m0 = *reinterpret_cast<const f32x4v*>(&mdl[sn][0]);
         m1 = *reinterpret_cast<const f32x4v*>(&mdl[sn][4]);
         m2 = *reinterpret_cast<const f32x2*>(&mdl[sn][8]);
+        const ModelS ms = model_to_sgprs(c0, c1, c2);
         unsigned long long va[KM], vb[KM];
+#ifdef PM_RF_SCALAR_FMA
+        const float fs[9] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3], c2[0]};
+#endif
 #pragma unroll
         for (int k = 0; k < KM; ++k) {
             bool ia, ib;
-            inlier_pk_model<KIND>(c0, c1, c2, X[k], Y[k], XP[k], YP[k], thr2, ia, ib);
+#ifdef PM_RF_SCALAR_FMA
+            ia = inlier32<KIND>(fs, X[k][0], Y[k][0], XP[k][0], YP[k][0], thr2);
+            ib = inlier32<KIND>(fs, X[k][1], Y[k][1], XP[k][1], YP[k][1], thr2);
+#else
+            inlier_pk_model<KIND>(ms, X[k], Y[k], XP[k], YP[k], thr2, ia, ib);
+#endif
             va[k] = __ballot(ia);
             vb[k] = __ballot(ib);
         }
@@ -212,6 +241,7 @@ __device__ __forceinline__ void score_tile(const float (*__restrict__ mdl)[12], 
     }
 }
 
+template <int NWAVES>
 __device__ __forceinline__ unsigned long long wg_max_u64(unsigned long long key, unsigned long long* __restrict__ wk, int tid)
 {
     key = pm::wave_max_u64(key);
@@ -220,7 +250,7 @@ __device__ __forceinline__ unsigned long long wg_max_u64(unsigned long long key,
     __syncthreads();
     unsigned long long k = wk[0];
 #pragma unroll
-    for (int w = 1; w < RF_THREADS / 64; ++w) k = wk[w] > k ? wk[w] : k;
+    for (int w = 1; w < NWAVES; ++w) k = wk[w] > k ? wk[w] : k;
     return k;
 }
 
@@ -241,20 +271,22 @@ __device__ unsigned long long g_rf_stamps[4096 * 12];
 
 // ---- the kernel ------------------------------------------------------------------------------------------------
 template <int KIND, int PPT2>
-__global__ __launch_bounds__(RF_THREADS) void ransac_fused(pm_points_view v, uint64_t seed, int64_t hyp_begin, int nh, int hb,
+__global__ __launch_bounds__(RF_WG) void ransac_fused(pm_points_view v, uint64_t seed, int64_t hyp_begin, int nh, int hb,
                                                            float thr2, RfSlot* __restrict__ slots, int* __restrict__ ticket,
                                                            RfOut out)
 {
     __shared__ __attribute__((aligned(16))) float s_mdl[RF_HB_MAX][12];    // f32 model + valid flag of hypothesis s
     __shared__ double s_m64[RF_HB_MAX][9];
-    __shared__ int s_cnt[RF_THREADS / 64][RF_HB_MAX];
+    __shared__ int s_cnt[RF_THREADS / 64][RF_HB_MAX];         // [wave of the scoring team][hypothesis]
     __shared__ int s_offs[PM_MAX_PARTS + 1];
-    __shared__ unsigned long long s_wk[RF_THREADS / 64];
+    __shared__ unsigned long long s_wk[RF_WG / 64];
     __shared__ double s_F64[9];
     __shared__ int s_role;
     __shared__ int s_wc[RF_THREADS / 64];
 
+    // tid: thread of the workgroup; ttid / twave: thread / wave inside its team (the tile geometry is a team's)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int team = tid / RF_THREADS, ttid = tid % RF_THREADS, twave = wave % (RF_THREADS / 64);
     RF_STAMP(0);
     int n;
     if (v.parts == 1) {
@@ -281,7 +313,7 @@ __global__ __launch_bounds__(RF_THREADS) void ransac_fused(pm_points_view v, uin
         for (int k = 0; k < PPT2; ++k) {
             X[k] = f32x2{nanv, nanv}; Y[k] = X[k]; XP[k] = X[k]; YP[k] = X[k];
             if (k < kmax) {                                      // workgroup-uniform
-                const int i0 = base + 2 * (k * RF_THREADS + tid);
+                const int i0 = base + 2 * (k * RF_THREADS + ttid);
                 float2 a0 = {nanv, nanv}, b0 = a0, a1 = a0, b1 = a0;
                 if (v.parts == 1) {
                     // plain array: unconditional clamped loads (n >= 1 here), all of a tile's requests in flight together
@@ -302,7 +334,6 @@ __global__ __launch_bounds__(RF_THREADS) void ransac_fused(pm_points_view v, uin
         }
         return kmax;
     };
-    int kmax = load_tile(0);
     RF_STAMP(2);
 
     // ---- solve: lane s solves hypothesis h0 + s (SPEC S6, S7); models stay in LDS
@@ -323,6 +354,9 @@ __global__ __launch_bounds__(RF_THREADS) void ransac_fused(pm_points_view v, uin
         s_mdl[tid][10] = 0.f; s_mdl[tid][11] = 0.f;
     }
     RF_STAMP(3);
+    // the tile is loaded AFTER the solve: its 40 registers would otherwise be live (spilled) across the solver, which
+    // alone decides the kernel's register count (128 at four waves per SIMD)
+    int kmax = load_tile(0);
     __syncthreads();
     RF_STAMP(4);
 
@@ -330,11 +364,11 @@ __global__ __launch_bounds__(RF_THREADS) void ransac_fused(pm_points_view v, uin
     for (int t = 0; t < ntiles; ++t) {
         if (t > 0) kmax = load_tile(t);
         switch (kmax) {                                      // workgroup-uniform
-#define PM_CASE(KM_) case KM_: score_tile<KIND, PPT2, (KM_ <= PPT2 ? KM_ : PPT2)>(s_mdl, s_cnt, hcount, X, Y, XP, YP, thr2, t == 0, lane, wave); break;
+#define PM_CASE(KM_) case KM_: score_tile<KIND, PPT2, (KM_ <= PPT2 ? KM_ : PPT2)>(s_mdl, s_cnt, hcount, X, Y, XP, YP, thr2, t == 0, lane, twave, team); break;
             PM_CASE(1) PM_CASE(2) PM_CASE(3) PM_CASE(4) PM_CASE(5) PM_CASE(6) PM_CASE(7) PM_CASE(8) PM_CASE(9) PM_CASE(10)
 #undef PM_CASE
             default:
-                for (int s = lane; s < hcount; s += 64) s_cnt[wave][s] = t == 0 ? 0 : s_cnt[wave][s];   // empty tile (n == 0)
+                if (team == 0) for (int s = lane; s < hcount; s += 64) s_cnt[twave][s] = t == 0 ? 0 : s_cnt[twave][s];   // empty tile (n == 0)
                 break;
         }
     }
@@ -350,7 +384,7 @@ __global__ __launch_bounds__(RF_THREADS) void ransac_fused(pm_points_view v, uin
         key = (static_cast<unsigned long long>(static_cast<uint32_t>(c)) << 32) |
               static_cast<unsigned long long>(0xFFFFFFFFu - static_cast<uint32_t>(hyp_begin + h0 + tid));
     }
-    const unsigned long long kbest = wg_max_u64(key, s_wk, tid);
+    const unsigned long long kbest = wg_max_u64<RF_WG / 64>(key, s_wk, tid);
     if (wave == 0) {
         const int sb = kbest ? static_cast<int>(static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(kbest)) - hyp_begin) - h0 : 0;
         RfSlot* sl = slots + blockIdx.x;
@@ -374,7 +408,7 @@ __global__ __launch_bounds__(RF_THREADS) void ransac_fused(pm_points_view v, uin
     double fb[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) fb[i] = 0.0;
-    for (int j = tid; j < static_cast<int>(gridDim.x); j += RF_THREADS) {
+    for (int j = tid; j < static_cast<int>(gridDim.x); j += RF_WG) {
         const unsigned long long kj = __hip_atomic_load(&slots[j].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         double fj[9];
 #pragma unroll
@@ -385,7 +419,7 @@ __global__ __launch_bounds__(RF_THREADS) void ransac_fused(pm_points_view v, uin
             for (int i = 0; i < 9; ++i) fb[i] = fj[i];
         }
     }
-    const unsigned long long kwin = wg_max_u64(kb, s_wk, tid);
+    const unsigned long long kwin = wg_max_u64<RF_WG / 64>(kb, s_wk, tid);
     const bool ok = kwin != 0ull && n >= 8;
     if (tid < 9) s_F64[tid] = 0.0;
     __syncthreads();
@@ -412,24 +446,26 @@ __global__ __launch_bounds__(RF_THREADS) void ransac_fused(pm_points_view v, uin
 #pragma unroll
     for (int i = 0; i < 9; ++i) fw[i] = static_cast<float>(s_F64[i]);
     int mine = 0;
-    for (int t = 0; t < ntiles; ++t) {
-        if (ntiles > 1) kmax = load_tile(t);                 // a single tile is still in the registers
+    if (team == 0) {                                         // team 0's registers cover every correspondence
+        for (int t = 0; t < ntiles; ++t) {
+            if (ntiles > 1) kmax = load_tile(t);             // a single tile is still in the registers
 #pragma unroll
-        for (int k = 0; k < PPT2; ++k) {
-            if (k < kmax) {
-                bool ia, ib;
-                inlier32_x2_flags<KIND>(fw, X[k], Y[k], XP[k], YP[k], thr2, ia, ib);
-                ia = ia && ok; ib = ib && ok;
-                const int i0 = t * RF_TILE + 2 * (k * RF_THREADS + tid);
-                if (i0 < out.mask_len) out.mask[i0] = ia ? 1 : 0;
-                if (i0 + 1 < out.mask_len) out.mask[i0 + 1] = ib ? 1 : 0;
-                mine += __popcll(__ballot(ia)) + __popcll(__ballot(ib));     // wave-uniform
+            for (int k = 0; k < PPT2; ++k) {
+                if (k < kmax) {
+                    bool ia, ib;
+                    inlier32_x2_flags<KIND>(fw, X[k], Y[k], XP[k], YP[k], thr2, ia, ib);
+                    ia = ia && ok; ib = ib && ok;
+                    const int i0 = t * RF_TILE + 2 * (k * RF_THREADS + ttid);
+                    if (i0 < out.mask_len) out.mask[i0] = ia ? 1 : 0;
+                    if (i0 + 1 < out.mask_len) out.mask[i0 + 1] = ib ? 1 : 0;
+                    mine += __popcll(__ballot(ia)) + __popcll(__ballot(ib));     // wave-uniform
+                }
             }
         }
+        if (lane == 0) s_wc[twave] = mine;
     }
     const int covered = n > 0 ? (n + RF_PTS_PER_SLOT - 1) / RF_PTS_PER_SLOT * RF_PTS_PER_SLOT : 0;
-    for (int i = covered + tid; i < out.mask_len; i += RF_THREADS) out.mask[i] = 0;
-    if (lane == 0) s_wc[wave] = mine;
+    for (int i = covered + tid; i < out.mask_len; i += RF_WG) out.mask[i] = 0;
     __syncthreads();
     if (tid == 0) {
         int tot = 0;
@@ -459,7 +495,7 @@ __global__ __launch_bounds__(RF_THREADS) void ransac_finish(pm_points_view v, co
     if (v.parts > 1) view_offsets(v, s_offs, tid);
     unsigned long long kb = 0ull;
     for (int j = tid; j < nrec; j += RF_THREADS) { const unsigned long long kj = recs[j].key; kb = kj > kb ? kj : kb; }
-    const unsigned long long kwin = wg_max_u64(kb, s_wk, tid);          // (its barriers also publish s_offs)
+    const unsigned long long kwin = wg_max_u64<RF_THREADS / 64>(kb, s_wk, tid);   // (its barriers also publish s_offs)
     const int n = v.parts > 1 ? s_offs[v.parts] : view_count1(v);
     const bool ok = kwin != 0ull && n >= 8;
     int owner = 0;
@@ -525,11 +561,13 @@ int sync_words(pm_ctx* ctx, int** out)
 
 }  // namespace
 
-// Hypothesis ids per workgroup: whole rounds of TWO workgroups per CU (a lone wave issues a VALU instruction every
-// 4-8 cycles; two waves per SIMD fill the vector pipe: score phase 19 -> 8 us at C3), at most RF_HB_MAX ids each.
+// Hypothesis ids per workgroup: whole rounds of one 512-thread workgroup per CU (two teams of four waves: a lone wave
+// issues a VALU instruction every 4-8 cycles, two per SIMD fill the vector pipe, and keeping both in ONE workgroup keeps
+// them in step — with two 256-thread workgroups per CU the second one's fp64 solve overlapped the first one's scoring
+// and stretched the slowest workgroup's score phase from 17k to 25k cycles), at most RF_HB_MAX ids each.
 int fused_hb(const pm_ctx* ctx, long long nh)
 {
-    const long long wgs = 2LL * ctx->n_cu;
+    const long long wgs = ctx->n_cu;
     const long long per_round = wgs * RF_HB_MAX;
     const long long rounds = (nh + per_round - 1) / per_round;
     long long hb = (nh + wgs * rounds - 1) / (wgs * rounds);
@@ -572,7 +610,7 @@ int fused_launch(pm_ctx* ctx, const pm_points_view& v, const pm_ransac_params* p
     pm::ScopedKernelTime t(ctx, "ransac_fused");
     // 2*RF_PPT2 points per thread: a 2560-point tile (config C3 fits one); small capacities take the 2-slot build
 #define PM_RF(KIND_, PPT2_)                                                                                              \
-    hipLaunchKernelGGL((ransac_fused<KIND_, PPT2_>), dim3(nwg), dim3(RF_THREADS), 0, ctx->stream, v, p->seed, p->hyp_begin, \
+    hipLaunchKernelGGL((ransac_fused<KIND_, PPT2_>), dim3(nwg), dim3(RF_WG), 0, ctx->stream, v, p->seed, p->hyp_begin, \
                        static_cast<int>(nh), hb, thr2, slots, sync, out)
     const int depth = cap_total <= 2 * RF_PTS_PER_SLOT ? 2 : (cap_total <= RF_PPT2 * RF_PTS_PER_SLOT ? RF_PPT2 : RF_PPT2_BIG);
 #define PM_RF_K(KIND_)                                                                   \

@@ -7,7 +7,11 @@ python -m points_matching_amd.build > /dev/null
 B=points_matching_amd/build
 mkdir -p $B/abl
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Iinclude -Ipoints_matching_amd/csrc"
-/opt/rocm/bin/hipcc $F -DPM_RF_STAMPS -x hip -c points_matching_amd/csrc/ransac_fused.hip -o /tmp/rf_stamps.o
 objs=$(ls $B/*.o | grep -v ransac_fused.o)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $B/abl/libpm_rfstamps.so /tmp/rf_stamps.o $objs
+/opt/rocm/bin/hipcc $F -DPM_RF_STAMPS -x hip -c points_matching_amd/csrc/ransac_fused.hip -o /tmp/rf_stamps.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $B/abl/libpm_rfstamps.so /tmp/rf_stamps.o $objs -ldl
 echo built $B/abl/libpm_rfstamps.so
+# experiment: unpacked v_fma_f32 scoring instead of v_pk_fma_f32 (same bits)
+/opt/rocm/bin/hipcc $F -DPM_RF_STAMPS -DPM_RF_SCALAR_FMA -x hip -c points_matching_amd/csrc/ransac_fused.hip -o /tmp/rf_stamps2.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $B/abl/libpm_rfstamps_scalar.so /tmp/rf_stamps2.o $objs -ldl
+echo built $B/abl/libpm_rfstamps_scalar.so
