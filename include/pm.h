@@ -69,7 +69,7 @@ int  pm_ctx_synchronize(pm_ctx* ctx);
  * "knn_l2_mfma", "knn_l2_refine", "knn_l2_exact", "knn_hamming_expand", "knn_hamming_mfma_i8",
  * "knn_hamming_refine", "knn_hamming", "knn_hamming_merge", "filter_gather", "concat_points",
  * "ransac_fused", "ransac_finish", "ransac_solve", "ransac_score", "ransac_select", "ransac_final", "lmeds_solve", "lmeds_median",
- * "lmeds_final", "fm_count". */
+ * "lmeds_final", "fm_count", "flann_search". */
 int  pm_ctx_timing_enable(pm_ctx* ctx, int enable);
 int  pm_ctx_timing_reset(pm_ctx* ctx);
 int  pm_ctx_timing_get(pm_ctx* ctx, const char* kernel, double* mean_ms, int* launches);
@@ -131,6 +131,29 @@ int pm_bf_knn_l2_f32_dev(pm_ctx* ctx, const float* d_q, int nq, const float* d_t
 int pm_bf_knn_l2_ratio_dev(pm_ctx* ctx, const float* d_q, int nq, const float* d_t, int nt, int dim, int flags,
                            float ratio, const float* d_kp1_xy, const float* d_kp2_xy, pm_match* d_knn,
                            pm_match* d_good, float* d_xy1, float* d_xy2, int32_t* d_n_good);
+
+/* ---- approximate matcher compatible with `FlannBasedMatcher matcher;` (main.cpp:44, the reference's ACTIVE matcher,
+ * called at main.cpp:46) — SURVEY.md 8f-4, docs/SPEC.md S17.  cv::flann defaults: 4 randomised kd-trees
+ * (KDTreeIndexParams(4)), 32 checks, eps 0, sorted results (SearchParams(32, 0, true)).  The forest is built on the
+ * host from the train descriptors (every random draw comes from a counter-based stream keyed by `seed`, not from C
+ * rand(): reproducible everywhere), uploaded once, and searched on the GPU (one lane per query, best-bin-first over
+ * all trees with one heap).  Output records like pm_bf_knn_l2_f32 (distance = sqrt of the canonical squared L2), rows
+ * ascending; with fewer than k examined points the tail has trainIdx = -1.  1 <= k <= 4.
+ * Approximate by design: tests report recall against the exact matcher; the exact matcher is also faster at the
+ * reference's sizes, so this path exists for behavioural compatibility (pm_cli --matcher flann). */
+typedef struct pm_flann_params {
+    int32_t  trees;     /* <= 0: 4 */
+    int32_t  checks;    /* <= 0: 32 */
+    uint64_t seed;
+} pm_flann_params;
+typedef struct pm_flann_index pm_flann_index;   /* opaque; bound to the context's device */
+int pm_flann_build(pm_ctx* ctx, const float* train, int nt, int dim, const pm_flann_params* prm, pm_flann_index** out);
+int pm_flann_destroy(pm_flann_index* ix);
+int pm_flann_knn_l2_f32(pm_ctx* ctx, pm_flann_index* ix, const float* q, int nq, int k, pm_match* out);
+int pm_flann_knn_l2_f32_dev(pm_ctx* ctx, pm_flann_index* ix, const float* d_q, int nq, int k, pm_match* d_out);
+/* The forest as built (tests, inspection): *n_nodes records of 16 bytes {int32 child1, child2 (-1: leaf), int32 cut
+ * dimension | point id of a leaf, float cut value}; roots[t] = root record of tree t.  nodes may be NULL (size query). */
+int pm_flann_export(const pm_flann_index* ix, int32_t* n_nodes, int32_t* roots, void* nodes, int32_t cap_nodes);
 
 /* Binary descriptors (ORB-256 = 32 bytes/row): Hamming distance, popcount of XOR.
  * `bytes` must be a multiple of 4.  Replaces main.cpp:46 for BASELINE config C4.  32-byte

@@ -871,3 +871,119 @@ int pmo_epiline_endpoints(const float* lines, int n, int cols, int32_t* xyxy)
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * SPEC S17 — search of a FLANN-style kd-forest (what `FlannBasedMatcher matcher;` at main.cpp:44 does behind
+ * matcher.match at main.cpp:46 [recalled: FLANN 1.6.11's KDTreeIndex::getNeighbors / searchLevel, checks = 32,
+ * eps = 0]).  Written recursively over a node pointer walk with an explicit array heap, i.e. NOT in the shape of the
+ * HIP kernel (iterative descent, interleaved heap): an independent restatement of the same algorithm over the SAME
+ * forest (pm_flann_export).  The forest's construction is checked by structural properties in the tests.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct pmo_flann_node { int32_t child1, child2, divfeat; float divval; } pmo_flann_node;
+
+typedef struct fl_state {
+    const pmo_flann_node* nodes;
+    const float* T; int dim, k, checks;
+    const float* q;
+    float rd[16]; int ri[16]; int rcount;
+    float* hd; int* hn; int hcount, hcap;
+    uint8_t* checked; int check_count;
+} fl_state;
+
+/* heap order: (bound, node id) — the id breaks ties, so the pop order does not depend on the heap's internals */
+static int fl_before(const fl_state* s, int a, int b)
+{
+    return s->hd[a] < s->hd[b] || (s->hd[a] == s->hd[b] && s->hn[a] < s->hn[b]);
+}
+
+static void fl_heap_push(fl_state* s, float d, int node)
+{
+    if (s->hcount >= s->hcap) return;
+    int i = s->hcount++;
+    s->hd[i] = d; s->hn[i] = node;
+    while (i > 0) {
+        int p = (i - 1) / 2;
+        if (!fl_before(s, i, p)) break;
+        float td = s->hd[p]; s->hd[p] = s->hd[i]; s->hd[i] = td;
+        int tn = s->hn[p]; s->hn[p] = s->hn[i]; s->hn[i] = tn;
+        i = p;
+    }
+}
+
+static int fl_heap_pop(fl_state* s, float* d, int* node)
+{
+    if (s->hcount == 0) return 0;
+    *d = s->hd[0]; *node = s->hn[0];
+    s->hcount--;
+    if (s->hcount > 0) {
+        s->hd[0] = s->hd[s->hcount]; s->hn[0] = s->hn[s->hcount];
+        int i = 0;
+        for (;;) {
+            int l = 2 * i + 1, r = l + 1, m = i;
+            if (l < s->hcount && fl_before(s, l, m)) m = l;
+            if (r < s->hcount && fl_before(s, r, m)) m = r;
+            if (m == i) break;
+            float td = s->hd[m]; s->hd[m] = s->hd[i]; s->hd[i] = td;
+            int tn = s->hn[m]; s->hn[m] = s->hn[i]; s->hn[i] = tn;
+            i = m;
+        }
+    }
+    return 1;
+}
+
+static void fl_search_level(fl_state* s, int node, float mindist)
+{
+    const float worst = s->rd[s->k - 1];
+    if (worst < mindist) return;
+    const pmo_flann_node* nd = &s->nodes[node];
+    if (nd->child1 < 0) {
+        const int idx = nd->divfeat;
+        if (s->checked[idx] || (s->check_count >= s->checks && s->rcount >= s->k)) return;
+        s->checked[idx] = 1;
+        s->check_count++;
+        const float d = pmo_l2sqr(s->q, s->T + (size_t)idx * s->dim, s->dim);
+        if (d < s->rd[s->k - 1]) {                  /* KNNResultSet::addPoint: behind equal distances */
+            int p = s->k - 1;
+            while (p > 0 && s->rd[p - 1] > d) { s->rd[p] = s->rd[p - 1]; s->ri[p] = s->ri[p - 1]; --p; }
+            s->rd[p] = d; s->ri[p] = idx;
+            if (s->rcount < s->k) s->rcount++;
+        }
+        return;
+    }
+    const float val = s->q[nd->divfeat];
+    const float diff = val - nd->divval;
+    const int best = diff < 0.f ? nd->child1 : nd->child2;
+    const int other = diff < 0.f ? nd->child2 : nd->child1;
+    const float p = diff * diff;
+    const float new_d = mindist + p;
+    if (new_d < s->rd[s->k - 1] || s->rcount < s->k) fl_heap_push(s, new_d, other);
+    fl_search_level(s, best, mindist);
+}
+
+int pmo_flann_search(const pmo_flann_node* nodes, const int32_t* roots, int trees, const float* T, int nt, int dim,
+                     const float* Q, int nq, int k, int checks, int heap_cap, pmo_match* out)
+{
+    if (k < 1 || k > 16 || trees < 1 || nt < 1) return -1;
+    float* hd = (float*)malloc(sizeof(float) * (size_t)heap_cap);
+    int* hn = (int*)malloc(sizeof(int) * (size_t)heap_cap);
+    uint8_t* checked = (uint8_t*)malloc((size_t)nt);
+    if (!hd || !hn || !checked) { free(hd); free(hn); free(checked); return -2; }
+    for (int i = 0; i < nq; ++i) {
+        fl_state s;
+        memset(&s, 0, sizeof s);
+        s.nodes = nodes; s.T = T; s.dim = dim; s.k = k; s.checks = checks; s.q = Q + (size_t)i * dim;
+        s.hd = hd; s.hn = hn; s.hcap = heap_cap; s.checked = checked;
+        memset(checked, 0, (size_t)nt);
+        for (int c = 0; c < 16; ++c) { s.rd[c] = INFINITY; s.ri[c] = -1; }
+        for (int t = 0; t < trees; ++t) fl_search_level(&s, roots[t], 0.f);
+        float bd; int bn;
+        while (fl_heap_pop(&s, &bd, &bn) && (s.check_count < checks || s.rcount < k)) fl_search_level(&s, bn, bd);
+        for (int c = 0; c < k; ++c) {
+            pmo_match* m = &out[(size_t)i * k + c];
+            m->queryIdx = i; m->imgIdx = 0; m->trainIdx = s.ri[c];
+            m->distance = s.ri[c] >= 0 ? sqrtf(s.rd[c]) : INFINITY;
+        }
+    }
+    free(hd); free(hn); free(checked);
+    return 0;
+}

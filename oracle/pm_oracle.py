@@ -264,3 +264,16 @@ def epiline_endpoints(lines, cols):
     out = np.zeros((lines.shape[0], 4), np.int32)
     lib().pmo_epiline_endpoints(_p(lines), lines.shape[0], cols, _p(out))
     return out
+
+
+def flann_search(nodes, roots, train, q, k=1, checks=32, heap_cap=1024):
+    """SPEC S17 search over an exported kd-forest (points_matching_amd.api.FlannIndex.export())."""
+    nodes = np.ascontiguousarray(nodes)
+    roots = np.ascontiguousarray(roots, np.int32)
+    train = np.ascontiguousarray(train, np.float32)
+    q = np.ascontiguousarray(q, np.float32)
+    out = np.zeros((q.shape[0], k), MATCH_DTYPE)
+    rc = lib().pmo_flann_search(_p(nodes), _p(roots), roots.size, _p(train), train.shape[0], train.shape[1], _p(q),
+                                q.shape[0], k, checks, heap_cap, _p(out))
+    assert rc == 0, rc
+    return out

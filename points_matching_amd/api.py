@@ -36,6 +36,7 @@ EXPORTS = [
     "pm_ransac_fundamental", "pm_ransac_score_dev", "pm_ransac_score_devn", "pm_ransac_model_from_hyp",
     "pm_ransac_model_from_key_dev", "pm_ransac_run_dev", "pm_ransac_shard_parts_dev", "pm_ransac_finish_parts_dev",
     "pm_ctx_set_option", "pm_ctx_get_option", "pm_bf_knn_l2_ratio_dev",
+    "pm_flann_build", "pm_flann_destroy", "pm_flann_knn_l2_f32", "pm_flann_knn_l2_f32_dev", "pm_flann_export",
     "pm_mgpu_create", "pm_mgpu_destroy", "pm_mgpu_size", "pm_mgpu_ctx", "pm_mgpu_ransac_fundamental", "pm_mgpu_match_ransac",
     "pm_batch_create", "pm_batch_destroy", "pm_batch_run", "pm_host_register", "pm_host_unregister",
     "pm_lmeds_fundamental", "pm_lmeds_fundamental_dev", "pm_lmeds_default_iters", "pm_ransac7_adaptive",
@@ -537,3 +538,51 @@ class MultiGpu:
         if rc not in (PM_OK, PM_E_NO_MODEL, PM_E_TOO_FEW):
             _check(rc)
         return rc, good[:ngood.value].copy(), F.reshape(3, 3), mask[:ngood.value].copy(), ninl.value, key.value
+
+
+# ---- FlannBasedMatcher-compatible approximate matcher (main.cpp:44; SPEC S17) ---------------------------
+
+class FlannParams(C.Structure):
+    _fields_ = [("trees", C.c_int32), ("checks", C.c_int32), ("seed", C.c_uint64)]
+
+
+FLANN_NODE_DTYPE = np.dtype([("child1", "<i4"), ("child2", "<i4"), ("divfeat", "<i4"), ("divval", "<f4")])
+
+
+class FlannIndex:
+    """pm_flann_index wrapper: kd-forest of the train descriptors (built on the host, searched on the GPU)."""
+
+    def __init__(self, ctx, train, trees=4, checks=32, seed=0):
+        self._ctx = ctx
+        self.train = np.ascontiguousarray(train, np.float32)
+        self.trees, self.checks = trees, checks
+        self._h = C.c_void_p()
+        prm = FlannParams(trees, checks, seed)
+        _check(lib().pm_flann_build(ctx._h, _p(self.train), self.train.shape[0], self.train.shape[1], C.byref(prm),
+                                    C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().pm_flann_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def knn(self, q, k=1):
+        q = np.ascontiguousarray(q, np.float32)
+        out = np.zeros((q.shape[0], k), MATCH_DTYPE)
+        _check(lib().pm_flann_knn_l2_f32(self._ctx._h, self._h, _p(q), q.shape[0], k, _p(out)))
+        return out
+
+    def export(self):
+        """(nodes structured array, roots int32[trees])"""
+        n = C.c_int32()
+        roots = np.zeros(16, np.int32)
+        _check(lib().pm_flann_export(self._h, C.byref(n), _p(roots), None, 0))
+        nodes = np.zeros(n.value, FLANN_NODE_DTYPE)
+        _check(lib().pm_flann_export(self._h, C.byref(n), _p(roots), _p(nodes), n.value))
+        return nodes, roots[:self.trees].copy()

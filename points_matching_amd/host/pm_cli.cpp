@@ -7,7 +7,9 @@
 //   pm_cli --desc1 a.pmm --desc2 b.pmm --kp1 ka.pmm --kp2 kb.pmm
 //          [--filter midpoint|ratio] [--ratio 0.8] [--iters 10000] [--thresh 1.0] [--seed 24301]
 //          [--method 7point-lmeds|ransac8] [--f-scale opencv|unit] [--device 0] [--gpus N] [--quiet] [--json]
-//          [--print-epilines] [--epilines out.ppm [--canvas W H] [--img2 right.pgm]]
+//          [--print-epilines] [--epilines out.ppm [--canvas W H] [--img2 right.pgm]] [--matcher bf|flann]
+// --matcher flann: the reference's ACTIVE matcher object (`FlannBasedMatcher matcher;`, main.cpp:44): 4 randomised
+// kd-trees, 32 checks (pm_flann_*; approximate, seeded by --seed); bf (default) is the exact matcher of main.cpp:43.
 // --gpus N (> 1): matcher rows and hypothesis ids are sharded over N GPUs through pm_mgpu_match_ransac (RCCL behind
 // the C ABI); needs --filter ratio --method ransac8 (the sharded form of the path, BASELINE config C4).
 // --print-epilines / --epilines: main.cpp:127-142 — the epipolar lines of the image-1 points in image 2
@@ -143,7 +145,7 @@ int main(int argc, char** argv)
     long iters = 10000;
     unsigned long long seed = 0x5EED;
     int device = 0, gpus = 1, canvas_w = 993, canvas_h = 660;       // canvas default: the size of img01/img02
-    std::string epi_ppm, img2_path;
+    std::string epi_ppm, img2_path, matcher = "bf";
     bool quiet = false, json = false, iters_given = false, print_epi = false, force_mgpu = false;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -164,6 +166,7 @@ int main(int argc, char** argv)
         else if (a == "--method") method = val("--method");
         else if (a == "--device") device = atoi(val("--device"));
         else if (a == "--gpus") gpus = atoi(val("--gpus"));
+        else if (a == "--matcher") matcher = val("--matcher");
         else if (a == "--mgpu") force_mgpu = true;            // take the pm_mgpu path even with --gpus 1 (tests)
         else if (a == "--print-epilines") print_epi = true;
         else if (a == "--epilines") epi_ppm = val("--epilines");
@@ -194,6 +197,11 @@ int main(int argc, char** argv)
         return 2;
     }
     if (gpus < 1 || canvas_w < 1 || canvas_h < 1) { fprintf(stderr, "pm_cli: bad --gpus / --canvas\n"); return 2; }
+    if (matcher != "bf" && matcher != "flann") { fprintf(stderr, "pm_cli: --matcher bf|flann\n"); return 2; }
+    if (matcher == "flann" && (d1.dtype != 0 || gpus > 1 || force_mgpu)) {
+        fprintf(stderr, "pm_cli: --matcher flann needs float32 descriptors and a single GPU\n");
+        return 2;
+    }
 
     using clk = std::chrono::steady_clock;
     pm_ctx* ctx = nullptr;
@@ -246,7 +254,14 @@ int main(int argc, char** argv)
     // ---- matcher.match(imageDesc1, imageDesc2, matchePoints, Mat())            main.cpp:42-46
     const int k = want_ratio ? 2 : 1;
     std::vector<pm_match> knn(static_cast<size_t>(d1.rows) * k);
-    if (d1.dtype == 0)
+    if (matcher == "flann") {
+        pm_flann_params fp;
+        fp.trees = 4; fp.checks = 32; fp.seed = seed;               // cv::flann defaults behind main.cpp:44
+        pm_flann_index* ix = nullptr;
+        rc = pm_flann_build(ctx, d2.f32(), d2.rows, d2.cols, &fp, &ix);
+        if (rc == PM_OK) rc = pm_flann_knn_l2_f32(ctx, ix, d1.f32(), d1.rows, k, knn.data());
+        pm_flann_destroy(ix);
+    } else if (d1.dtype == 0)
         rc = pm_bf_knn_l2_f32(ctx, d1.f32(), d1.rows, d2.f32(), d2.rows, d1.cols, k, 0, knn.data());
     else
         rc = pm_bf_knn_hamming_u8(ctx, d1.data.data(), d1.rows, d2.data.data(), d2.rows, d1.cols, k, knn.data());

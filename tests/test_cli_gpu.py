@@ -127,3 +127,21 @@ def test_cli_mgpu_path_equals_single_device_path(tmp_path):
     ja, jb = json.loads(la[-1]), json.loads(lb[-1])
     for k in ("matches", "inliers", "best_hyp", "F", "mean_abs_x1Fx2"):
         assert ja[k] == jb[k], k
+
+
+def test_cli_flann_matcher_is_the_reference_literal_flow(tmp_path, ctx, oracle):
+    """--matcher flann --filter midpoint --method 7point-lmeds = what main.cpp:44-98 literally does (FlannBasedMatcher,
+    midpoint filter, CV_FM_7POINT).  The printed list is the midpoint filter of the kd-forest's 1-NN matches."""
+    import points_matching_amd as pm
+    w = synth.pair_workload(nq=400, nt=380, dim=128, seed=21, planted=0.6, kind="surf")
+    cmd = _write_inputs(tmp_path, w) + ["--matcher", "flann", "--seed", "9", "--json"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.splitlines()
+    ix = pm.api.FlannIndex(ctx, w["t"], trees=4, checks=32, seed=9)
+    knn = ix.knn(w["q"], 1).reshape(-1)
+    good, mn, mx = oracle.filter_midpoint(knn)
+    exp = ["The Best Match is? " + _g(mn), "The Worst Match is? " + _g(mx)] + oracle.format_match_list(good).splitlines()
+    assert lines[:len(exp)] == exp
+    js = json.loads(lines[-1])
+    assert js["matches"] == good.size
