@@ -67,17 +67,20 @@ def build(force=False, verbose=False, extra_flags=()):
     return LIB
 
 
-HOST_SRC = os.path.join(HERE, "host", "pm_cli.cpp")
-HOST_BIN = os.path.join(HERE, "host", "pm_cli")
+HOST_DIR = os.path.join(HERE, "host")
+HOST_SRC = os.path.join(HOST_DIR, "pm_cli.cpp")
+HOST_SRCS = [HOST_SRC, os.path.join(HOST_DIR, "pm_features.cpp")]
+HOST_BIN = os.path.join(HOST_DIR, "pm_cli")
 
 
 def build_host(force=False):
     """C++ host tool (the counterpart of the reference's main()); links libpm_hip.so."""
     if not os.path.exists(HOST_SRC):
         return None
-    if force or _newer(HOST_SRC, HOST_BIN) or _newer(LIB, HOST_BIN):
-        cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), HOST_SRC,
-               "-o", HOST_BIN, "-L" + HERE, "-lpm_hip", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + HERE]
+    deps = HOST_SRCS + [os.path.join(HOST_DIR, "pm_features.hpp"), os.path.join(ROOT, "include", "pm.h"), LIB]
+    if force or any(_newer(d, HOST_BIN) for d in deps):
+        cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-I" + HOST_DIR] + HOST_SRCS + \
+              ["-o", HOST_BIN, "-L" + HERE, "-lpm_hip", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + HERE]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("host build failed:\n%s\n%s" % (" ".join(cmd), r.stderr))

@@ -1,10 +1,12 @@
 // pm_cli — C++ host of the MI355X-native matcher: the counterpart of the reference's main()
 // (`Points Matching/main.cpp:9-147`) for the hot path main.cpp:42-123.  It keeps the reference's
 // stdout surface (main.cpp:58-59, :73, :76, :119, :123) and calls the HIP kernels only through
-// the C ABI of include/pm.h.  Image decoding and SURF (main.cpp:11-40) are out of scope
-// (DESIGN.md §0): descriptors and keypoints come from binary matrix files.
+// the C ABI of include/pm.h.  Images come as binary PGM/PPM (no JPEG/BMP decoder in this image: `convert a.jpg a.pgm`
+// or PIL does it) and go through the build-owned detector/descriptor of pm_features.cpp (the
+// reference's SURF, main.cpp:22-40, is OpenCV nonfree code); descriptors and keypoints can also come from matrix files.
 //
-//   pm_cli --desc1 a.pmm --desc2 b.pmm --kp1 ka.pmm --kp2 kb.pmm
+//   pm_cli --img1 left.pgm --img2 right.pgm [--max-kp 4000]        (image pair in: main.cpp:14-15, :22-40)
+//   pm_cli --desc1 a.pmm --desc2 b.pmm --kp1 ka.pmm --kp2 kb.pmm   (descriptor pair in)
 //          [--filter midpoint|ratio] [--ratio 0.8] [--iters 10000] [--thresh 1.0] [--seed 24301]
 //          [--method 7point-lmeds|ransac8] [--f-scale opencv|unit] [--device 0] [--gpus N] [--quiet] [--json]
 //          [--print-epilines] [--epilines out.ppm [--canvas W H] [--img2 right.pgm]] [--matcher bf|flann]
@@ -31,6 +33,7 @@
 #include <vector>
 
 #include "pm.h"
+#include "pm_features.hpp"
 
 namespace {
 
@@ -130,6 +133,16 @@ bool write_epiline_ppm(const std::string& path, const std::vector<unsigned char>
     return ok;
 }
 
+bool save_matrix(const std::string& path, const Matrix& m)
+{
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) { fprintf(stderr, "pm_cli: cannot write %s\n", path.c_str()); return false; }
+    const int32_t hdr[3] = {m.rows, m.cols, m.dtype};
+    const bool ok = fwrite("PMM1", 1, 4, f) == 4 && fwrite(hdr, 4, 3, f) == 3 && fwrite(m.data.data(), 1, m.data.size(), f) == m.data.size();
+    fclose(f);
+    return ok;
+}
+
 int fail(const char* what, int rc)
 {
     fprintf(stderr, "pm_cli: %s failed: %s (%s)\n", what, pm_status_string(rc), pm_last_error());
@@ -145,7 +158,9 @@ int main(int argc, char** argv)
     long iters = 10000;
     unsigned long long seed = 0x5EED;
     int device = 0, gpus = 1, canvas_w = 993, canvas_h = 660;       // canvas default: the size of img01/img02
-    std::string epi_ppm, img2_path, matcher = "bf";
+    std::string epi_ppm, img2_path, matcher = "bf", img1_path, save_prefix;
+    bool extract_only = false;
+    int max_kp = 4000;
     bool quiet = false, json = false, iters_given = false, print_epi = false, force_mgpu = false;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -171,22 +186,58 @@ int main(int argc, char** argv)
         else if (a == "--print-epilines") print_epi = true;
         else if (a == "--epilines") epi_ppm = val("--epilines");
         else if (a == "--img2") img2_path = val("--img2");
+        else if (a == "--img1") img1_path = val("--img1");
+        else if (a == "--max-kp") max_kp = atoi(val("--max-kp"));
+        else if (a == "--save-features") save_prefix = val("--save-features");   // PREFIX_{desc1,desc2,kp1,kp2}.pmm
+        else if (a == "--extract-only") extract_only = true;                     // stop after the feature front-end (no GPU needed)
         else if (a == "--canvas") { canvas_w = atoi(val("--canvas")); canvas_h = atoi(val("--canvas")); }
         else if (a == "--quiet") quiet = true;
         else if (a == "--json") json = true;
         else { fprintf(stderr, "pm_cli: unknown option %s\n", a.c_str()); return 2; }
     }
+    Matrix d1, d2, k1, k2;
+    const bool from_images = !img1_path.empty();
+    if (from_images) {
+        // ---- imread + detect + compute                                          main.cpp:14-15, :22-26, :36-40
+        if (img2_path.empty() || max_kp < 8) { fprintf(stderr, "pm_cli: --img1 needs --img2 (and --max-kp >= 8)\n"); return 2; }
+        const std::string* paths[2] = {&img1_path, &img2_path};
+        Matrix* dm[2] = {&d1, &d2};
+        Matrix* km[2] = {&k1, &k2};
+        for (int i = 0; i < 2; ++i) {
+            pm_feat::Image im;
+            std::string err;
+            if (!pm_feat::load_pnm_gray(*paths[i], im, err)) { fprintf(stderr, "pm_cli: %s\n", err.c_str()); return 1; }
+            const pm_feat::Features ft = pm_feat::detect_and_describe(im, max_kp);
+            dm[i]->rows = ft.n; dm[i]->cols = 128; dm[i]->dtype = 0;
+            dm[i]->data.assign(reinterpret_cast<const unsigned char*>(ft.desc.data()),
+                               reinterpret_cast<const unsigned char*>(ft.desc.data()) + ft.desc.size() * sizeof(float));
+            km[i]->rows = ft.n; km[i]->cols = 2; km[i]->dtype = 0;
+            km[i]->data.assign(reinterpret_cast<const unsigned char*>(ft.kp_xy.data()),
+                               reinterpret_cast<const unsigned char*>(ft.kp_xy.data()) + ft.kp_xy.size() * sizeof(float));
+            if (!quiet) fprintf(stderr, "pm_cli: %s: %d x %d, %d keypoints\n", paths[i]->c_str(), im.w, im.h, ft.n);
+            if (i == 1) { canvas_w = im.w; canvas_h = im.h; }
+        }
+        if (!save_prefix.empty()) {
+            const Matrix* ms[4] = {&d1, &d2, &k1, &k2};
+            const char* names[4] = {"_desc1.pmm", "_desc2.pmm", "_kp1.pmm", "_kp2.pmm"};
+            for (int i = 0; i < 4; ++i)
+                if (!save_matrix(save_prefix + names[i], *ms[i])) return 1;
+        }
+        if (extract_only) return 0;
+        if (d1.rows < 8 || d2.rows < 8) { fprintf(stderr, "pm_cli: too few keypoints\n"); return 1; }
+    } else {
     if (desc1.empty() || desc2.empty() || kp1.empty() || kp2.empty()) {
-        fprintf(stderr, "usage: pm_cli --desc1 A --desc2 B --kp1 KA --kp2 KB [--filter midpoint|ratio] "
-                        "[--ratio r] [--iters n] [--thresh px] [--seed s] [--f-scale opencv|unit]\n");
+        fprintf(stderr, "usage: pm_cli (--img1 L.pgm --img2 R.pgm | --desc1 A --desc2 B --kp1 KA --kp2 KB) [--filter midpoint|ratio] "
+                        "[--ratio r] [--method 7point-lmeds|ransac8] [--iters n] [--thresh px] [--seed s] [--f-scale opencv|unit] "
+                        "[--matcher bf|flann] [--gpus N] [--print-epilines] [--epilines out.ppm] [--json] [--quiet]\n");
         return 2;
     }
-    Matrix d1, d2, k1, k2;
     if (!load_matrix(desc1, d1) || !load_matrix(desc2, d2) || !load_matrix(kp1, k1) || !load_matrix(kp2, k2)) return 1;
     if (d1.cols != d2.cols || d1.dtype != d2.dtype || k1.dtype != 0 || k2.dtype != 0 || k1.cols != 2 ||
         k2.cols != 2 || k1.rows != d1.rows || k2.rows != d2.rows) {
         fprintf(stderr, "pm_cli: inconsistent descriptor / keypoint matrices\n");
         return 1;
+    }
     }
     const bool want_ratio = filter == "ratio";
     if (method != "ransac8" && method != "7point-lmeds") { fprintf(stderr, "pm_cli: --method ransac8|7point-lmeds\n"); return 2; }

@@ -52,6 +52,21 @@ def main():
     out.update(mid_query=g1["queryIdx"], mid_train=g1["trainIdx"], mid_minmax=np.array([mn, mx]),
                mid_F_bits=F.reshape(9).view(np.uint64), mid_mask=mask, mid_key=np.array([key], np.uint64))
     np.savez_compressed(os.path.join(HERE, "img01_img02_sift.npz"), **out)
+    # image-pair-in fixtures for the C++ front-end (host/pm_features.cpp, pm_cli --img1/--img2): the two photographs at
+    # half resolution as binary PGM (data derived from the reference's JPEGs; 164 KB each) and what the numpy twin of
+    # the extractor (tools/sift_numpy.py) finds in exactly these pixels
+    half = {}
+    for name, src in (("img01", "img01.JPG"), ("img02", "img02.JPG")):
+        im = Image.open(os.path.join(REF, src)).convert("L")
+        im = im.resize((im.width // 2, im.height // 2), Image.BILINEAR)
+        a = np.asarray(im, np.uint8)
+        with open(os.path.join(HERE, name + "_half.pgm"), "wb") as f:
+            f.write(b"P5\n%d %d\n255\n" % (a.shape[1], a.shape[0]))
+            f.write(a.tobytes())
+        kp, d = detect_and_describe(a.astype(np.float32) / 255.0)
+        half[name + "_kp"], half[name + "_desc"] = kp, d
+    np.savez_compressed(os.path.join(HERE, "img01_img02_half_features.npz"), **half)
+    print("half resolution: %d / %d keypoints" % (half["img01_kp"].shape[0], half["img02_kp"].shape[0]))
     print("img01/img02: %d x %d keypoints, ratio matches %d (inliers %d), midpoint matches %d (inliers %d)"
           % (kp1.shape[0], kp2.shape[0], good.size, ninl, g1.size, ninl2))
 

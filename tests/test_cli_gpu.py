@@ -145,3 +145,28 @@ def test_cli_flann_matcher_is_the_reference_literal_flow(tmp_path, ctx, oracle):
     assert lines[:len(exp)] == exp
     js = json.loads(lines[-1])
     assert js["matches"] == good.size
+
+
+def test_cli_image_pair_in(tmp_path):
+    """Image pair in, match list + F + epiline overlay out (the reference's whole surface, main.cpp:14-143) on the
+    reference's own two photographs (half-resolution PGM fixtures)."""
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    ppm = str(tmp_path / "epi.ppm")
+    cmd = [build.HOST_BIN, "--img1", os.path.join(gold, "img01_half.pgm"), "--img2", os.path.join(gold, "img02_half.pgm"),
+           "--filter", "ratio", "--method", "ransac8", "--iters", "5000", "--json", "--epilines", ppm]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.splitlines()
+    js = json.loads(lines[-1])
+    assert lines[0] == "Good Matches are:" and js["matches"] >= 60 and js["inliers"] >= 0.6 * js["matches"]
+    assert js["mean_abs_x2Fx1"] < 5.0
+    raw = open(ppm, "rb").read()
+    assert raw.startswith(b"P6\n496 330\n255\n")
+    px = np.frombuffer(raw[len(b"P6\n496 330\n255\n"):], np.uint8).reshape(330, 496, 3)
+    assert (px == 255).all(axis=2).sum() > 496                      # epipolar lines drawn over the right image
+    assert len(np.unique(px[..., 0])) > 50                           # ... which is still there under them
+    # the reference's literal configuration (FlannBasedMatcher, midpoint filter, CV_FM_7POINT) also runs end to end
+    out2 = subprocess.run(cmd[:5] + ["--matcher", "flann", "--json"], capture_output=True, text=True, timeout=300)
+    assert out2.returncode == 0, out2.stderr
+    js2 = json.loads(out2.stdout.splitlines()[-1])
+    assert js2["matches"] >= 8
