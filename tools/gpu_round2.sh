@@ -1,0 +1,44 @@
+#!/bin/bash
+# Round-2 measurement session on the GPU box: bench lines of every config, the N > 1 path with two ranks on one GPU,
+# rocprofv3 kernel traces, PMC passes (each counter group in its own run, never with sys/hip/hsa traces).
+# usage (through gpurun): bash tools/gpu_round2.sh <tag>
+set -o pipefail
+TAG=${1:-r2}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+step() {   # step <name> <seconds> <cmd...>
+    local name=$1 secs=$2; shift 2
+    timeout -k 10 $secs "$@"
+    local rc=$?
+    echo "$name rc=$rc"
+    if [ $rc -ge 124 ]; then echo "$name timed out / was killed: stopping"; ls $O; exit $rc; fi
+    return 0
+}
+step bench_c3 300 bash -c "python bench.py > $O/bench_c3.json 2> $O/bench_c3.err"
+step bench_c2 300 bash -c "python bench.py --workload c2 --no-cpu-baseline > $O/bench_c2.json 2> $O/bench_c2.err"
+step bench_c4 300 bash -c "python bench.py --workload c4 > $O/bench_c4.json 2> $O/bench_c4.err"
+step bench_c5 300 bash -c "python bench.py --workload c5 --steps 5 --warmup 5 > $O/bench_c5.json 2> $O/bench_c5.err"
+step bench_surf 300 bash -c "python bench.py --kind surf --no-cpu-baseline > $O/bench_c3_surf.json 2> $O/bench_c3_surf.err"
+step bench_x1 300 bash -c "python bench.py --exercise-exchange --no-cpu-baseline > $O/bench_c3_exchange_world1.json 2> $O/bench_c3_exchange_world1.err"
+step bench_w2 300 bash -c "python bench.py --gpus 2 --backend gloo --single-device --steps 5 --warmup 2 --no-cpu-baseline --sustain-seconds 0 > $O/bench_c3_world2_gloo.json 2> $O/bench_c3_world2_gloo.err"
+step bench_w2s 300 bash -c "python bench.py --gpus 2 --backend gloo --single-device --workload c4 --scaling strong --steps 5 --warmup 2 --no-cpu-baseline --sustain-seconds 0 > $O/bench_c4_strong_world2_gloo.json 2> $O/bench_c4_strong_world2_gloo.err"
+cd /tmp && export TMPDIR=/tmp
+step trace_c3 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c3 -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-verify --sustain-seconds 0 > $O/trace_c3.log 2>&1
+step trace_c4 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c4 -- python3 $R/bench.py --workload c4 --steps 10 --warmup 3 --no-cpu-baseline --no-verify --sustain-seconds 0 > $O/trace_c4.log 2>&1
+pass() {   # pass <dir> <driver + args> -- <counters...>
+    local name=$1 drv=$2; shift 2
+    timeout -k 10 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$name -- python3 $R/tools/$drv > $O/$name.log 2>&1
+    local rc=$?
+    echo "$name rc=$rc"; tail -1 $O/$name.log
+    if [ $rc -ge 124 ]; then echo "timed out: stopping"; exit $rc; fi
+}
+for d in "knn:prof_knn.py" "ransac:prof_ransac.py" "ham:prof_hamming.py"; do
+  n=${d%%:*}; drv=${d##*:}
+  pass pmc_${n}/sq1 $drv SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS
+  pass pmc_${n}/sq2 $drv SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_MFMA GRBM_GUI_ACTIVE
+  pass pmc_${n}/fetch $drv FETCH_SIZE
+  pass pmc_${n}/write $drv WRITE_SIZE
+done
+ls $O
