@@ -84,6 +84,7 @@ def bench_c5(args, world, rank, local_rank, dev, multi, saved_stdout):
         h = hold[i % distinct]
         jobs.append((h["q"].data_ptr(), n, h["t"].data_ptr(), n, h["kp1"].data_ptr(), h["kp2"].data_ptr()))
     batch = pm.api.PairBatch(local_rank, args.lanes, n, n, dim)
+    batch.set_option(pm.api.PM_OPT_RANSAC_PATH, args.ransac_path)
     arr = batch.make_jobs(jobs)
     flags = pm.api.PM_KNN_HINT_INTEGER
 

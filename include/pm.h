@@ -366,6 +366,7 @@ typedef struct pm_pair_result {
 typedef struct pm_batch pm_batch;   /* opaque */
 int pm_batch_create(int device, int n_lanes, int max_n1, int max_n2, int dim, pm_batch** out);
 int pm_batch_destroy(pm_batch* b);
+int pm_batch_set_option(pm_batch* b, int option, int value);     /* pm_ctx_set_option on every lane's context */
 int pm_batch_run(pm_batch* b, const pm_pair_job* jobs, int n_jobs, float ratio, int knn_flags,
                  const pm_ransac_params* p, pm_pair_result* results, pm_match* good, uint8_t* masks);
 /* Page-lock / release a caller-owned host buffer (hipHostRegister) so the batch copies overlap. */

@@ -38,7 +38,7 @@ EXPORTS = [
     "pm_ctx_set_option", "pm_ctx_get_option", "pm_bf_knn_l2_ratio_dev",
     "pm_flann_build", "pm_flann_destroy", "pm_flann_knn_l2_f32", "pm_flann_knn_l2_f32_dev", "pm_flann_export",
     "pm_mgpu_create", "pm_mgpu_destroy", "pm_mgpu_size", "pm_mgpu_ctx", "pm_mgpu_ransac_fundamental", "pm_mgpu_match_ransac",
-    "pm_batch_create", "pm_batch_destroy", "pm_batch_run", "pm_host_register", "pm_host_unregister",
+    "pm_batch_create", "pm_batch_destroy", "pm_batch_run", "pm_batch_set_option", "pm_host_register", "pm_host_unregister",
     "pm_lmeds_fundamental", "pm_lmeds_fundamental_dev", "pm_lmeds_default_iters", "pm_ransac7_adaptive",
     "pm_epipolar_residuals", "pm_f_scale_f33", "pm_epilines", "pm_epiline_endpoints",
 ]
@@ -453,6 +453,9 @@ class PairBatch:
             self.close()
         except Exception:
             pass
+
+    def set_option(self, option, value):
+        _check(lib().pm_batch_set_option(self._h, option, value))
 
     @staticmethod
     def make_jobs(jobs):

@@ -120,6 +120,16 @@ extern "C" int pm_batch_create(int device, int n_lanes, int max_n1, int max_n2, 
     return PM_OK;
 }
 
+extern "C" int pm_batch_set_option(pm_batch* b, int option, int value)
+{
+    PM_REQUIRE(b != nullptr, PM_E_INVALID, "batch is null");
+    for (int i = 0; i < b->n_lanes; ++i) {
+        const int rc = pm_ctx_set_option(b->lanes[i].ctx, option, value);
+        if (rc != PM_OK) return rc;
+    }
+    return PM_OK;
+}
+
 extern "C" int pm_batch_destroy(pm_batch* b)
 {
     if (!b) return PM_OK;

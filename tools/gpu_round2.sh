@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-2 measurement session on the GPU box: bench lines of every config, the N > 1 path with two ranks on one GPU,
 # rocprofv3 kernel traces, PMC passes (each counter group in its own run, never with sys/hip/hsa traces).
-# usage (through gpurun): bash tools/gpu_round2.sh <tag>
+# usage (through gpurun): bash tools/gpu_round2.sh <tag> [pmc-only]
 set -o pipefail
 TAG=${1:-r2}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -16,6 +16,7 @@ step() {   # step <name> <seconds> <cmd...>
     if [ $rc -ge 124 ]; then echo "$name timed out / was killed: stopping"; ls $O; exit $rc; fi
     return 0
 }
+if [ "$2" != "pmc-only" ]; then
 step bench_c3 300 bash -c "python bench.py > $O/bench_c3.json 2> $O/bench_c3.err"
 step bench_c2 300 bash -c "python bench.py --workload c2 --no-cpu-baseline > $O/bench_c2.json 2> $O/bench_c2.err"
 step bench_c4 300 bash -c "python bench.py --workload c4 > $O/bench_c4.json 2> $O/bench_c4.err"
@@ -27,8 +28,10 @@ step bench_w2s 300 bash -c "python bench.py --gpus 2 --backend gloo --single-dev
 cd /tmp && export TMPDIR=/tmp
 step trace_c3 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c3 -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-verify --sustain-seconds 0 > $O/trace_c3.log 2>&1
 step trace_c4 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c4 -- python3 $R/bench.py --workload c4 --steps 10 --warmup 3 --no-cpu-baseline --no-verify --sustain-seconds 0 > $O/trace_c4.log 2>&1
+fi
 pass() {   # pass <dir> <driver + args> -- <counters...>
     local name=$1 drv=$2; shift 2
+    mkdir -p $(dirname $O/$name)
     timeout -k 10 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$name -- python3 $R/tools/$drv > $O/$name.log 2>&1
     local rc=$?
     echo "$name rc=$rc"; tail -1 $O/$name.log
