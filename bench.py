@@ -287,11 +287,7 @@ def main():
     # One contiguous "survivor block" per rank: [count (int32) + 3 pad words | xy1: nq x 2 f32 | xy2: nq x 2 f32].
     # The filter writes straight into it, so the N>1 exchange before RANSAC is ONE all-gather of this block and
     # RANSAC reads the gathered blocks through a pm_points_view (no concatenation pass).
-    blk_words = 4 + 4 * nq
-    d_blk = torch.zeros(blk_words, dtype=torch.float32, device=dev)
-    d_n = d_blk[0:1].view(torch.int32)
-    d_xy1 = d_blk[4:4 + 2 * nq].view(nq, 2)
-    d_xy2 = d_blk[4 + 2 * nq:].view(nq, 2)
+    d_blk, d_n, d_xy1, d_xy2 = shard.survivor_block(nq, dev)
     d_key = torch.zeros(1, dtype=torch.int64, device=dev)
     n_all_max = nq * world
     d_F = torch.zeros(9, dtype=torch.float64, device=dev)
@@ -299,11 +295,10 @@ def main():
     d_ninl = torch.zeros(1, dtype=torch.int32, device=dev)
     d_ntot = torch.zeros(1, dtype=torch.int32, device=dev)
     if multi:
-        g_blk = torch.zeros((world, blk_words), dtype=torch.float32, device=dev)
+        g_blk = torch.zeros((world, d_blk.numel()), dtype=torch.float32, device=dev)
         d_rec = torch.zeros(10, dtype=torch.float64, device=dev)             # pm_ransac_record: key + F[9]
         g_rec = torch.zeros((world, 10), dtype=torch.float64, device=dev)
-        view = pm.api.PointsView(g_blk.data_ptr() + 16, g_blk.data_ptr() + 16 + 8 * nq, g_blk.data_ptr(), world, nq,
-                                 blk_words, blk_words, 0)
+        view = shard.view_of_blocks(g_blk, nq)
     hb, he = shard.hyp_shard(H, rank, world)
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
@@ -462,10 +457,7 @@ def main():
         ok = (got["trainIdx"][rows] == want["trainIdx"]).all() and \
              (got["distance"][rows].view(np.uint32) == want["distance"].view(np.uint32)).all()
         if multi:                                  # the concatenation the view stands for, done here for the checker only
-            gb = g_blk.cpu()
-            cnt = gb[:, 0:1].view(torch.int32).reshape(-1).tolist()
-            xs1 = np.concatenate([gb[p, 4:4 + 2 * nq].view(nq, 2)[:cnt[p]].numpy() for p in range(world)])
-            xs2 = np.concatenate([gb[p, 4 + 2 * nq:].view(nq, 2)[:cnt[p]].numpy() for p in range(world)])
+            xs1, xs2, _ = shard.concat_blocks(g_blk, nq)
         else:
             xs1 = d_xy1[:n_m].cpu().numpy()
             xs2 = d_xy2[:n_m].cpu().numpy()

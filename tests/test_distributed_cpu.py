@@ -1,7 +1,8 @@
-"""CPU, world_size 2, gloo: the N>1 plumbing of the path (points_matching_amd/shard.py) —
-hypothesis-id sharding + the single 8-byte all-reduce(max), and the all-gather of the
-query-row-sharded matcher's survivors.  The per-rank compute is the oracle here (the HIP kernels
-need a GPU); what is under test is that the exchange reproduces the unsharded answer."""
+"""CPU, world_size 2, gloo: the N>1 plumbing of the path (points_matching_amd/shard.py) — query-row sharding with ONE
+all-gather of the survivor blocks, hypothesis-id sharding with ONE all-gather of the 80-byte (key, F) records, winner =
+largest key.  The per-rank compute is the oracle here (the HIP kernels need a GPU; tests/test_bench_gpu.py runs the same
+exchange through them with two ranks on one GPU); what is under test is that the exchange reproduces the unsharded
+answer."""
 import os
 import sys
 
@@ -25,25 +26,28 @@ def _worker(rank, world, port, q):
         w = synth.pair_workload(nq, nt, 64, seed=31, rank=rank, planted=0.5, kind="surf")
         knn = O.bf_knn_l2(w["q"], w["t"], 2)
         good = O.filter_ratio(knn, 0.8)
-        xy1 = np.zeros((nq, 2), np.float32)
-        xy2 = np.zeros((nq, 2), np.float32)
-        xy1[:good.size] = O.gather_points(w["kp1"], good["queryIdx"])
-        xy2[:good.size] = O.gather_points(w["kp2"], good["trainIdx"])
-        g1 = torch.zeros((world, nq, 2))
-        g2 = torch.zeros((world, nq, 2))
-        gn = torch.zeros(world, dtype=torch.int32)
-        shard.gather_blocks(torch.from_numpy(xy1), torch.from_numpy(xy2),
-                            torch.tensor([good.size], dtype=torch.int32), g1, g2, gn)
-        a1, a2 = shard.concat_blocks_reference(g1, g2, gn)
-        a1, a2 = a1.numpy(), a2.numpy()
+        # exchange 1: the survivor block (count | xy1 | xy2), one all-gather
+        blk, n, xy1, xy2 = shard.survivor_block(nq, "cpu")
+        n[0] = good.size
+        xy1[:good.size] = torch.from_numpy(O.gather_points(w["kp1"], good["queryIdx"]))
+        xy2[:good.size] = torch.from_numpy(O.gather_points(w["kp2"], good["trainIdx"]))
+        g_blk = torch.zeros((world, blk.numel()), dtype=torch.float32)
+        dist.all_gather_into_tensor(g_blk.view(-1), blk)
+        a1, a2, cnt = shard.concat_blocks(g_blk, nq)
+        view = shard.view_of_blocks(g_blk, nq)
+        # this rank's hypothesis ids over ALL correspondences -> its 80-byte record
         hb, he = shard.hyp_shard(H, rank, world)
-        rc, _, _, _, key = O.ransac_fundamental(a1, a2, he, 1.0, 77, hyp_begin=hb)
-        kt = torch.tensor([key], dtype=torch.int64)
-        shard.reduce_key(kt)
+        rc, F_r, _, _, key_r = O.ransac_fundamental(a1, a2, he, 1.0, 77, hyp_begin=hb)
+        rec = torch.from_numpy(shard.make_record(key_r, F_r))
+        # exchange 2: the records, one all-gather; every rank picks the largest key's model
+        g_rec = torch.zeros((world, 10), dtype=torch.float64)
+        dist.all_gather_into_tensor(g_rec.view(-1), rec)
+        key, F = shard.pick_record(g_rec.numpy())
         full = O.ransac_fundamental(a1, a2, H, 1.0, 77)
-        rc2, F, mask, n = O.ransac_model_from_hyp(a1, a2, 0xFFFFFFFF - (int(kt) & 0xFFFFFFFF), 1.0, 77)
-        q.put((rank, int(gn.sum()), int(gn[rank]) == good.size, int(kt) == full[4],
-               bool((F == full[1]).all() and (mask == full[2]).all()), (hb, he), a1.tobytes()))
+        cnt_o, mask = O.score(F.astype(np.float32), a1, a2, 1.0)
+        q.put((rank, sum(cnt), cnt[rank] == good.size, key == full[4],
+               bool((F.view(np.uint64) == full[1].view(np.uint64)).all() and (mask == full[2]).all() and cnt_o == full[3]),
+               (hb, he), a1.tobytes(), (view.parts, view.cap, view.pitch_xy)))
     finally:
         dist.destroy_process_group()
 
@@ -60,9 +64,19 @@ def test_world2_gloo_sharded_path_equals_unsharded():
         assert p.exitcode == 0, 'worker failed'
     res = sorted(q.get(timeout=10) for _ in range(world))
     assert res[0][1] == res[1][1] > 100            # same global correspondence count on both ranks
-    assert all(r[2] and r[3] and r[4] for r in res)
+    assert all(r[2] and r[3] and r[4] for r in res)  # winner key, model bits, mask and count = the unsharded run's
     assert res[0][5] == (0, 200) and res[1][5] == (200, 400)
     assert res[0][6] == res[1][6]                  # identical gathered correspondences, in rank order
+    assert res[0][7] == (2, 512, 4 + 4 * 512)
+
+
+def test_row_shard_partitions():
+    from points_matching_amd import shard
+    for n in (1, 7, 8192, 32768, 1001):
+        for world in (1, 2, 3, 8):
+            r = [shard.row_shard(n, g, world) for g in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[i][1] == r[i + 1][0] for i in range(world - 1))
 
 
 def test_hyp_shard_partitions():
