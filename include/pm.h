@@ -86,6 +86,7 @@ enum {
     PM_OPT_HAMMING_ROUTE  = 3,  /* 1: integer-VALU scan, 2: matrix-core route with 64-bit refinement keys          */
     PM_OPT_KNN_F16_WAVES  = 4,  /* f16/i8 coarse kernel: 1 = 8 waves x 32 queries, 2 = 4 waves x 64 queries        */
     PM_OPT_KNN_STAGING    = 6,  /* f16/i8 coarse kernel, train tiles: 1 = through registers, 2 = LDS-DMA (default)  */
+    PM_OPT_KNN_WG_PER_CU  = 7,  /* f16 coarse kernel: train splits sized for 1 (default) or 2 workgroups per CU     */
     PM_OPT_FILTER_FUSION  = 5,  /* pm_bf_knn_l2_ratio_dev: 1 = filter as its own launch, 2 = inside the refinement  */
     PM_OPT_COUNT_         = 8
 };

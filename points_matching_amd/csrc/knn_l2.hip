@@ -882,7 +882,11 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
     {
         const int nqb = nq_pad / H_QB;
         const int ntiles = nt_pad / H_TT;
-        int splits = (2 * ctx->n_cu + nqb - 1) / nqb;
+        // train splits sized for ONE workgroup per CU: with LDS-DMA staging a lone workgroup keeps the matrix pipe as busy as
+        // two co-resident ones did with register staging (C3: 18.9 vs 19.0-21.7 us, 4096 x 4096: 10.0 vs 11.6 us), and half
+        // the splits are half the candidate lists the refinement has to read.  PM_OPT_KNN_WG_PER_CU = 2: two per CU.
+        const int wg_per_cu = ctx->opts[PM_OPT_KNN_WG_PER_CU] == 2 ? 2 : 1;
+        int splits = (wg_per_cu * ctx->n_cu + nqb - 1) / nqb;
         if (splits < (ntiles + 15) / 16) splits = (ntiles + 15) / 16;          // <= 2048 rows per split (see above)
         if (splits > ntiles) splits = ntiles;
         if (splits > 64) splits = 64;
