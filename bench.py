@@ -359,21 +359,18 @@ def main():
     sustained = None
     if args.sustain_seconds > 0:
         n_sus = max(args.steps, int(args.sustain_seconds / max(ms_per_step * 1e-3, 1e-6)) + 1)
-        es = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        ms_acc, cnt = 0.0, 0
+        es = []                                      # stage split measured on the last K steps of the run
         fence()
         t0 = time.perf_counter()
         for i in range(n_sus):
-            last = i >= n_sus - args.steps          # stage split measured on the last K steps of the run
-            if last:
-                ev2 = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-                step(ev2)
-                es.append(ev2)
+            if i >= n_sus - args.steps:
+                es.append([torch.cuda.Event(enable_timing=True) for _ in range(3)])
+                step(es[-1])
             else:
                 step()
         fence()
         t_sus = time.perf_counter() - t0
-        m_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in es[2:]]))
+        m_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in es]))
         if multi:
             tt = torch.tensor([t_sus, m_ms], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)

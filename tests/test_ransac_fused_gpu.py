@@ -117,3 +117,22 @@ def test_many_hypotheses_and_every_register_depth(ctx, oracle):
         assert got[4] == want[4] and got[3] == want[3], n
         assert (got[2] == want[2]).all(), n
         assert (got[1].view(np.uint64) == want[1].view(np.uint64)).all(), n
+
+
+def test_automatic_path_choice_crosses_to_the_per_lane_kernels(ctx, oracle):
+    """ids x correspondences >= 2^30: the automatic rule hands the run to the hypothesis-per-lane kernels, whose own
+    automatic choice then takes the scalar-operand scorer (BASELINE config C4's shape on one GPU); just below the rule
+    the one-launch kernel runs.  Same bits either way."""
+    assert ctx.get_option(pm.api.PM_OPT_RANSAC_PATH) == 0 and ctx.get_option(pm.api.PM_OPT_SCORE_OPERANDS) == 0
+    for n, H in ((11000, 100000), (10000, 100000)):
+        x1, x2, _, _ = synth.two_view(n, seed=n, outlier_frac=0.35, noise_px=0.6)
+        ctx.timing_enable(True)
+        ctx.timing_reset()
+        got = ctx.ransac_fundamental(x1, x2, H, 1.0, 0xC4)
+        used_fused = ctx.timing_get("ransac_fused")[1] > 0
+        used_lane = ctx.timing_get("ransac_score")[1] > 0
+        ctx.timing_enable(False)
+        assert used_fused == (n * H < 2 ** 30) and used_lane == (n * H >= 2 ** 30), (n, H, used_fused, used_lane)
+        want = oracle.ransac_fundamental(x1, x2, H, 1.0, 0xC4, nthreads=16)
+        assert got[4] == want[4] and got[3] == want[3] and (got[2] == want[2]).all(), n
+        assert (got[1].view(np.uint64) == want[1].view(np.uint64)).all(), n
