@@ -117,3 +117,18 @@ def test_exhaustive_checks_equal_the_exact_matcher(ctx):
     same = (got["trainIdx"] == exact["trainIdx"]).all(axis=1)
     assert same.mean() > 0.99
     assert (got["distance"].view(np.uint32) == exact["distance"].view(np.uint32)).all()
+
+
+def test_flann_argument_checks(ctx):
+    w = synth.pair_workload(16, 40, 32, seed=1, kind="surf")
+    with pytest.raises(pm.PmError):
+        pm.api.FlannIndex(ctx, w["t"][:0])                          # empty train set
+    with pytest.raises(pm.PmError):
+        pm.api.FlannIndex(ctx, w["t"], trees=17)
+    ix = pm.api.FlannIndex(ctx, w["t"])
+    with pytest.raises(pm.PmError):
+        ix.knn(w["q"], 5)                                           # k > 4
+    assert ix.knn(w["q"][:0], 1).shape == (0, 1)
+    one = pm.api.FlannIndex(ctx, w["t"][:1])                        # a single train row: every query matches it, no 2nd neighbour
+    r = one.knn(w["q"], 2)
+    assert (r["trainIdx"][:, 0] == 0).all() and (r["trainIdx"][:, 1] == -1).all() and np.isinf(r["distance"][:, 1]).all()

@@ -136,3 +136,27 @@ def test_automatic_path_choice_crosses_to_the_per_lane_kernels(ctx, oracle):
         want = oracle.ransac_fundamental(x1, x2, H, 1.0, 0xC4, nthreads=16)
         assert got[4] == want[4] and got[3] == want[3] and (got[2] == want[2]).all(), n
         assert (got[1].view(np.uint64) == want[1].view(np.uint64)).all(), n
+
+
+def test_argument_checks_of_the_view_entry_points(ctx):
+    dev = torch.device("cuda", 0)
+    g = torch.zeros((2, 64, 2), dtype=torch.float32, device=dev)
+    cnt = torch.zeros(2, dtype=torch.int32, device=dev)
+    rec = torch.zeros(10, dtype=torch.float64, device=dev)
+    msk = torch.zeros(128, dtype=torch.uint8, device=dev)
+    good = PointsView(g.data_ptr(), g.data_ptr(), cnt.data_ptr(), 2, 64, 128, 1, 0)
+    with pytest.raises(pm.PmError):                      # more than PM_MAX_PARTS parts
+        ctx.ransac_shard_parts_dev(PointsView(g.data_ptr(), g.data_ptr(), cnt.data_ptr(), 65, 1, 2, 1, 0), 0, 10, 1.0, 1, rec.data_ptr())
+    with pytest.raises(pm.PmError):                      # pitch smaller than a part
+        ctx.ransac_shard_parts_dev(PointsView(g.data_ptr(), g.data_ptr(), cnt.data_ptr(), 2, 64, 100, 1, 0), 0, 10, 1.0, 1, rec.data_ptr())
+    with pytest.raises(pm.PmError):                      # empty hypothesis range
+        ctx.ransac_shard_parts_dev(good, 5, 5, 1.0, 1, rec.data_ptr())
+    with pytest.raises(pm.PmError):                      # unknown error kind
+        ctx.ransac_shard_parts_dev(good, 0, 10, 1.0, 1, rec.data_ptr(), kind=7)
+    with pytest.raises(pm.PmError):                      # no records
+        ctx.ransac_finish_parts_dev(good, 1.0, rec.data_ptr(), 0, 0, 0, msk.data_ptr(), 128, 0)
+    # an empty view (all counts zero) is data, not an error: zero record, zero mask
+    ctx.ransac_shard_parts_dev(good, 0, 10, 1.0, 1, rec.data_ptr())
+    ctx.ransac_finish_parts_dev(good, 1.0, rec.data_ptr(), 1, 0, 0, msk.data_ptr(), 128, 0)
+    ctx.synchronize()
+    assert not rec.cpu().numpy().any() and not msk.cpu().numpy().any()
