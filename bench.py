@@ -38,7 +38,7 @@ PEAK_F16_MFMA_TFLOPS = 2500.0    # dense f16/bf16 MFMA (spec; the 5 PF headline 
 def _kernel_source_sha():
     import hashlib
     h = hashlib.sha256()
-    for f in ("knn_coarse.hip", "knn_shared.hpp", "knn_l2.hip", "knn_hamming.hip"):
+    for f in ("knn_coarse.hip", "knn_coarse_kernels.hpp", "knn_shared.hpp", "knn_l2.hip", "knn_hamming.hip"):
         with open(os.path.join(ROOT, "points_matching_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

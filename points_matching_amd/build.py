@@ -16,7 +16,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libpm_hip.so")
-SOURCES = ["pm_capi.cpp", "knn_l2.hip", "knn_coarse.hip", "knn_hamming.hip", "ransac.hip", "ransac_fused.hip", "filter_gather.hip",
+SOURCES = ["pm_capi.cpp", "knn_l2.hip", "knn_coarse.hip", "knn_hamming.hip", "ransac.hip", "ransac_fused.hip", "ransac_shard.hip", "filter_gather.hip",
            "pair_batch.cpp", "lmeds.hip", "mgpu.cpp", "flann.hip"]
 # per-file extra flags: the coarse kernels only nominate candidates (no result bit depends on them)
 EXTRA = {"knn_coarse.hip": ["-ffinite-math-only"]}

@@ -1,0 +1,677 @@
+// knn_coarse_kernels.hpp — kernel bodies and launch templates of the two MFMA coarse passes of the L2 matcher and of
+// the Hamming matcher (see knn_l2.hip for the overall scheme and docs/SPEC.md S1b for the error bounds).  Replaces,
+// together with knn_l2.hip, `matcher.match(imageDesc1, imageDesc2, matchePoints, Mat())` (main.cpp:46).
+//
+// Everything is templated on an ablation policy.  Exactly two translation units include this header:
+// csrc/knn_coarse.hip (the product: policy AblNone, nothing else is instantiated) and
+// tools/ablation/knn_coarse_ablation.hip (timing-only variants for profiles/; never linked into libpm_hip.so).
+//
+// Built with -ffinite-math-only (see knn_shared.hpp).  Nothing in this file decides a result bit:
+// the coarse values only nominate candidate rows for the canonical refinement.
+#pragma once
+#include "knn_shared.hpp"
+
+namespace pm_knn {
+namespace {
+
+// Compile-time switches of the timing-only ablation builds ("what does a tile cost without ...": outputs are wrong).
+// The product instantiates every kernel with AblNone; the variants live in tools/ablation/knn_coarse_ablation.hip.
+// No preprocessor hooks.
+template <bool NO_EPI, bool NO_STAGE, bool NO_BARRIER, bool NO_LDSREAD>
+struct Abl {
+    static constexpr bool no_epi = NO_EPI;            // drop the in-chain selection (accumulators kept live)
+    static constexpr bool no_stage = NO_STAGE;        // do not stage the next tile
+    static constexpr bool no_barrier = NO_BARRIER;    // no workgroup barrier per tile
+    static constexpr bool no_ldsread = NO_LDSREAD;    // A fragments read once, not per chunk
+};
+typedef Abl<false, false, false, false> AblNone;
+
+template <typename ABL>
+__device__ __forceinline__ void tile_barrier()
+{
+    if constexpr (ABL::no_barrier) asm volatile("" ::: "memory");
+    else __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// coarse pass on the matrix cores
+//
+// Per (query, train row) the MFMA chain accumulates w = q.t - ||t||^2/2 = -(d2a - ||q||^2)/2 (the
+// seed -||t||^2/2 is one more k-step of the chain): the LARGEST w are the nearest rows.  The row's position in this lane's stream
+// (lid = tile_in_split*32 + block*16 + reg) is written into the low `bits` mantissa bits of w, so
+// a candidate is ONE float and keeping the 4 largest is branch-free:
+//     n0 = max(x,w0); n1 = med3(x,w0,w1); n2 = med3(x,w1,w2); n3 = med3(x,w2,w3)
+// (5 VALU per pair incl. the bit insert).  The truncation error 2^(bits-23)*|w| is part of the
+// refinement's window (SPEC S1b).  Two accumulator sets: the epilogue of tile t-1 is issued
+// between the MFMAs of tile t, so the matrix pipe does not wait for the selection.
+// ---------------------------------------------------------------------------------------------
+// (keep & w) | (~keep & id): the id lands in the low mantissa bits (hipcc emits v_bfi / v_and_or)
+__device__ __forceinline__ float embed_lid(float w, unsigned keep_mask, unsigned lid)
+{
+    return __uint_as_float((__float_as_uint(w) & keep_mask) | (lid & ~keep_mask));
+}
+
+// This translation unit is built with -ffinite-math-only: fmaxf / fmed3 then need no canonicalising
+// v_max in front of every operand (the operands ARE finite here: non-finite inputs divert to the
+// exact re-scan), and because these are compiler-visible instructions hipcc's hazard recogniser
+// keeps the required distance between an MFMA and the first VALU read of its result.  (An
+// earlier version used inline-asm v_max3/v_med3 directly on the accumulators: hipcc pads nothing
+// inside or in front of asm, and the f16 route then read accumulators one k-chunk early.)
+__device__ __forceinline__ void top4_insert(f32x4& c, float x)
+{
+    const float n0 = fmaxf(x, c[0]);
+    const float n1 = __builtin_amdgcn_fmed3f(x, c[0], c[1]);
+    const float n2 = __builtin_amdgcn_fmed3f(x, c[1], c[2]);
+    const float n3 = __builtin_amdgcn_fmed3f(x, c[2], c[3]);
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+// The two lane halves of a query column (lanes r and r + 32: rows 4h..4h+3 of every 8-row stripe) keep
+// separate lists while the sweep runs; at the end the half bit goes into bit 0 of every id and the two
+// sorted lists are merged into ONE list of 4 per (query, split) — half the candidate volume for the
+// refinement.  Once per kernel: four cross-half shuffles and four inserts.
+__device__ __forceinline__ void merge_halves(f32x4& cl, int h)
+{
+    f32x4 own, other;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        own[i] = __uint_as_float(__float_as_uint(cl[i]) | static_cast<unsigned>(h));
+        other[i] = __shfl_xor(own[i], 32, 64);
+    }
+    cl = own;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) top4_insert(cl, other[i]);
+}
+
+// GROUPED selection.  Registers 4g..4g+3 of an accumulator are four CONSECUTIVE train rows
+// (8g + 4*(lane>>5) + {0,1,2,3} of the 32-row block).  Only the group's largest w competes for the
+// list (2 VALU per 4 values: v_max3 + v_max), tagged with the GROUP id; the refinement
+// re-evaluates all four rows of a candidate group.  That is sound: a row inside the window has a
+// group maximum inside the window, and the k largest group maxima are attained by k distinct rows.
+// VALU cost per descriptor pair: (2 + 1 + 4) / 4 = 1.75 instead of 5 — the selection, not the
+// matrix pipe, is what bounds the f16 route.
+__device__ __forceinline__ float group_max(const f32x16& acc, int g)
+{
+    return fmaxf(fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), acc[4 * g + 2]), acc[4 * g + 3]);
+}
+
+// NCH = padded dim / 8; FULL = (dim == 8*NCH), which drops the column guards; TT = train rows
+// per LDS tile (64: two workgroups per CU, 128: one workgroup per CU with twice the MFMA work
+// between barriers).  grid = (ceil(nq/QB), splits).  Dynamic LDS: 2 tiles of TT x (8*NCH + 4)
+// floats (row stride padded by one 16-B slot: conflict-free ds_read_b128 for the 16 rows of a lane
+// group) + 2 x TT seeds (-||t||^2/2, or -KNN_BIG/2 past the last row).
+template <int NCH, bool FULL, int TT>
+struct KnnTile {
+    static constexpr int DP = NCH * 8;
+    static constexpr int LDT = DP + 4;
+    static constexpr int F4_PER_ROW = DP / 4;
+    static constexpr int NSTG = TT * F4_PER_ROW / 256;
+    static_assert(TT * F4_PER_ROW % 256 == 0, "tile must split evenly over the workgroup");
+
+    f32x4 stg[NSTG];
+    float stg_n;
+
+    // global -> registers (unconditional loads: clamped addresses, zero-select afterwards)
+    __device__ __forceinline__ void load(const float* __restrict__ T, const float* __restrict__ tnorm, int tile,
+                                         int nt, int dim, int tid)
+    {
+#pragma unroll
+        for (int i = 0; i < NSTG; ++i) {
+            const int f = tid + 256 * i;
+            const int row = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
+            int g = tile * TT + row;
+            g = g < nt ? g : nt - 1;
+            int col = 4 * c4;
+            if (!FULL) col = col < dim ? col : dim - 4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(T + static_cast<size_t>(g) * dim + col);
+            if (!FULL && 4 * c4 >= dim) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            stg[i] = v;
+        }
+        const int gn = tile * TT + (tid & (TT - 1));
+        const float nrm = tnorm[gn < nt ? gn : nt - 1];
+        stg_n = gn < nt ? -0.5f * nrm : -0.5f * KNN_BIG;
+    }
+    // registers -> LDS buffer
+    // the row seed -||t||^2/2 travels in the row's 16-byte pad slot: (seed, 0, 0, 0)
+    __device__ __forceinline__ void store(float* __restrict__ Ts, int buf, int tid) const
+    {
+#pragma unroll
+        for (int i = 0; i < NSTG; ++i) {
+            const int f = tid + 256 * i;
+            const int row = f / F4_PER_ROW, c4 = f % F4_PER_ROW;
+            *reinterpret_cast<f32x4*>(Ts + (buf * TT + row) * LDT + 4 * c4) = stg[i];
+        }
+        if (tid < TT) *reinterpret_cast<f32x4*>(Ts + (buf * TT + tid) * LDT + DP) = f32x4{stg_n, 0.f, 0.f, 0.f};
+    }
+};
+
+// One tile of the sweep.  Everything that is not an MFMA is issued INSIDE the chain, in the shadow
+// of a 64-cycle MFMA: the global loads of the next tile after chunk 0, the selection of the
+// previous tile's accumulators p[] spread over all chunks, and the LDS writes of the next tile
+// after the last-but-one chunk.  The row seed -||t||^2/2 enters through the matrix pipe as well:
+// one extra k-step per block multiplies the pad column (seed, 0) of the A tile by (1, 0), starting
+// from the inline constant C = 0, so no accumulator is initialised and the selection needs no
+// add.  The next tile is always staged (clamped addresses; past the end the data is unused),
+// which keeps the chain free of branches.
+// C[i][j] of lane (j = lane&31), register reg is train row i = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+template <int NCH, bool FULL, int NB, bool EPI, typename ABL>
+__device__ __forceinline__ void knn_tile_compute(float* __restrict__ Ts, int buf, int r, int h,
+                                                 const f32x4 (&qf)[NCH], f32x16 (&a)[NB], const f32x16 (&p)[NB],
+                                                 unsigned pbase, unsigned keep_mask, f32x4& cl,
+                                                 KnnTile<NCH, FULL, NB * 32>& st, const float* __restrict__ T,
+                                                 const float* __restrict__ tnorm, int next_tile, int nt, int dim,
+                                                 int tid)
+{
+    constexpr int DP = NCH * 8;
+    constexpr int LDT = DP + 4;
+    constexpr int TT = NB * 32;
+    static_assert(NCH >= 4, "the in-chain schedule needs at least 4 chunks");
+    const float* tb = Ts + buf * TT * LDT + r * LDT + 4 * h;
+    const float one_or_zero = h == 0 ? 1.f : 0.f;          // B side of the seed step: k = h
+    float sda[NB];                                          // A side: pad[h] = (seed, 0)[h]
+    f32x4 xn[NB];                                           // A fragments, one chunk ahead of their MFMAs
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+        sda[blk] = Ts[buf * TT * LDT + (32 * blk + r) * LDT + DP + h];
+        xn[blk] = *reinterpret_cast<const f32x4*>(tb + 32 * blk * LDT);
+    }
+    {
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk)
+            a[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(sda[blk], one_or_zero, zero, 0, 0, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        f32x4 x[NB];
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) x[blk] = xn[blk];
+        if constexpr (!ABL::no_ldsread) {
+            if (c + 1 < NCH) {
+#pragma unroll
+                for (int blk = 0; blk < NB; ++blk)
+                    xn[blk] = *reinterpret_cast<const f32x4*>(tb + 32 * blk * LDT + 8 * (c + 1));
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk)
+                a[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[blk][t], qf[c][t], a[blk], 0, 0, 0);
+        if constexpr (!ABL::no_stage) {
+            if (c == 0) st.load(T, tnorm, next_tile, nt, dim, tid);                   // global -> registers
+            if (c == NCH - 2) st.store(Ts, buf ^ 1, tid);                             // registers -> LDS
+        }
+        if (EPI && !ABL::no_epi) {
+            // row groups of the previous tile, spread over chunks 1..NCH-1 (chunk 0 is left alone so
+            // that a full round of this tile's MFMAs separates the previous tile's last MFMA from
+            // the first read of its accumulators)
+            constexpr int NG = 4 * NB;
+#pragma unroll
+            for (int g = (c == 0 ? 0 : (c - 1) * NG / (NCH - 1)); g < (c == 0 ? 0 : c * NG / (NCH - 1)); ++g)      // block g>>2, group g&3
+                top4_insert(cl, embed_lid(group_max(p[g >> 2], g & 3), keep_mask, (pbase + static_cast<unsigned>(g)) << 1));
+            // pin the selection to this chunk: without a use here hipcc sinks all of it below the
+            // MFMA chain (in front of the barrier), where nothing hides it.
+            asm volatile("" : "+v"(cl[0]), "+v"(cl[1]), "+v"(cl[2]), "+v"(cl[3]));
+        }
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void knn_select_all(const f32x16 (&p)[NB], unsigned pbase, unsigned keep_mask, f32x4& cl)
+{
+#pragma unroll
+    for (int g = 0; g < 4 * NB; ++g)
+        top4_insert(cl, embed_lid(group_max(p[g >> 2], g & 3), keep_mask, (pbase + static_cast<unsigned>(g)) << 1));
+}
+
+template <int NCH, bool FULL, int TT, typename ABL>
+__global__ __launch_bounds__(256, (TT == 64 ? 2 : 1)) void knn_l2_mfma(
+    const float* __restrict__ Q, const float* __restrict__ T, const float* __restrict__ tnorm, int nq,
+    int nt, int dim, int tiles_per_split, unsigned keep_mask, float* __restrict__ cand_val, int slots,
+    const unsigned long long* __restrict__ stats, unsigned epoch, int only_if_ineligible)
+{
+    if (only_if_ineligible) {                  // auto mode: the f16 route handles eligible data
+        const unsigned long long s1 = stats[1];
+        if (!(static_cast<unsigned>(s1 >> 32) == epoch && (s1 & 2ull))) return;
+    }
+    using Tile = KnnTile<NCH, FULL, TT>;
+    constexpr int LDT = Tile::LDT;
+    constexpr int NB = TT / 32;
+    constexpr unsigned IDS = 4 * NB;           // row-group ids a lane sees per tile
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ts = smem;                          // [2][TT][LDT], seed in each row's pad slot
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int qrow = blockIdx.x * QB + wave * 32 + r;
+    const int qld = qrow < nq ? qrow : nq - 1;
+
+    // B operand: this lane's query row, k = 8c + 4h + {0..3} for chunk c (the k permutation is
+    // shared with the A operand, and a dot product does not care about k order).
+    f32x4 qf[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int k0 = 8 * c + 4 * h;
+        int col = k0;
+        if (!FULL) col = col < dim ? col : dim - 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(Q + static_cast<size_t>(qld) * dim + col);
+        if (!FULL && k0 >= dim) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        qf[c] = v;
+    }
+
+    const int ntiles = (nt + TT - 1) / TT;
+    const int tile0 = blockIdx.y * tiles_per_split;
+    int tile1 = tile0 + tiles_per_split;
+    if (tile1 > ntiles) tile1 = ntiles;
+
+    f32x4 cl = {-KNN_BIG, -KNN_BIG, -KNN_BIG, -KNN_BIG};
+    if (tile0 < tile1) {                       // block-uniform
+        Tile st;
+        st.load(T, tnorm, tile0, nt, dim, tid);
+        st.store(Ts, 0, tid);
+        __syncthreads();
+
+        // every accumulator has a compile-time name: tiles alternate A, B, A, ...  (tix = tile - tile0)
+        f32x16 accA[NB], accB[NB];
+        int tix = 0;
+        const int ntl = tile1 - tile0;
+        knn_tile_compute<NCH, FULL, NB, false, ABL>(Ts, 0, r, h, qf, accA, accA, 0u, keep_mask, cl, st, T, tnorm,
+                                               tile0 + 1, nt, dim, tid);
+        tile_barrier<ABL>();
+        ++tix;
+        for (;;) {
+            if (tix >= ntl) { knn_select_all<NB>(accA, static_cast<unsigned>(tix - 1) * IDS, keep_mask, cl); break; }
+            // tile -> B while selecting A (tile-1)
+            knn_tile_compute<NCH, FULL, NB, true, ABL>(Ts, tix & 1, r, h, qf, accB, accA, static_cast<unsigned>(tix - 1) * IDS,
+                                                  keep_mask, cl, st, T, tnorm, tile0 + tix + 1, nt, dim, tid);
+            tile_barrier<ABL>();
+            ++tix;
+            if (tix >= ntl) { knn_select_all<NB>(accB, static_cast<unsigned>(tix - 1) * IDS, keep_mask, cl); break; }
+            // tile -> A while selecting B (tile-1)
+            knn_tile_compute<NCH, FULL, NB, true, ABL>(Ts, tix & 1, r, h, qf, accA, accB, static_cast<unsigned>(tix - 1) * IDS,
+                                                  keep_mask, cl, st, T, tnorm, tile0 + tix + 1, nt, dim, tid);
+            tile_barrier<ABL>();
+            ++tix;
+        }
+    }
+
+    merge_halves(cl, h);
+    if (qrow < nq && h == 0) {
+        const size_t o = static_cast<size_t>(qrow) * slots + blockIdx.y * KNN_C;
+        *reinterpret_cast<f32x4*>(cand_val + o) = cl;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// f16 route: integer-valued descriptors (what OpenCV's SIFT emits: 0..255 stored as float).
+// knn_l2_prep16 (knn_l2.hip) writes the padded f16 copies and verifies eligibility; see there.
+//
+// At this matrix rate the selection is as expensive as the MFMAs, so the kernel is organised
+// around it: a wave owns 64 queries (two B blocks: every A fragment read from LDS feeds two
+// MFMAs), walks the 128-row tile one 32-row block at a time and selects block b-1 between the
+// MFMAs of block b, with two alternating accumulator sets.
+// ---------------------------------------------------------------------------------------------
+// The kernel is shared by two routes with the same structure (rows of NCH k-chunks of 32 B, 16 B per
+// lane and MFMA; 288-byte rows with a seed chunk for f16, 256-byte rows for i8):
+//   RouteF16  v_mfma_f32_32x32x16_f16, values float, group id in the low mantissa bits;
+//   RouteI8   v_mfma_i32_32x32x32_i8 on +-1 bytes (binary descriptors: dot = bits - 2*hamming),
+//             values int, candidate = (dot << I8_SHIFT) | group id.
+// `par` is the f16 route's keep mask (unused by the i8 route: its shift is a constant).
+struct RouteF16 {
+    static constexpr int NCH = H_NCH;                 // 8 data chunks + the seed chunk
+    static constexpr int ROW16 = H_ROW16;             // 16-byte units per global row
+    static constexpr int LDS_ROW16 = H_LDS_ROW16;     // ... per LDS row (one pad slot)
+    static constexpr int GPB = 4;                     // row groups per 32-row block and lane: groups of 4 rows
+    static constexpr bool MERGE = true;               // one list per (query, split): float ties are rare
+    typedef f16x8 frag;
+    typedef f32x16 acc;
+    typedef f32x4 list;
+    static __device__ __forceinline__ acc zero()
+    {
+        return acc{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    }
+    static __device__ __forceinline__ acc mfma(frag a, frag b, acc c)
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ list empty() { return list{-KNN_BIG, -KNN_BIG, -KNN_BIG, -KNN_BIG}; }
+    static __device__ __forceinline__ void select(const acc& a, unsigned par, unsigned gid, list& cl, int g)
+    {
+        top4_insert(cl, embed_lid(group_max(a, g), par, gid));
+    }
+    static __device__ __forceinline__ void merge(list& cl, int h) { merge_halves(cl, h); }
+};
+
+struct RouteI8 {
+    static constexpr int NCH = I8_NCH;                // 8 data chunks, no seed: pad rows are all-zero (dot = 0)
+    static constexpr int ROW16 = I8_ROW16;
+    static constexpr int LDS_ROW16 = I8_LDS_ROW16;
+    static constexpr int GPB = 2;                     // groups of 8 rows: the popcount refinement is cheap
+    static constexpr bool MERGE = false;              // integer distances tie all the time: a 4-deep merged list would
+                                                      // overflow (and force split re-scans) for most queries
+    typedef i32x4 frag;
+    typedef i32x16 acc;
+    typedef i32x4 list;
+    static __device__ __forceinline__ acc zero() { return acc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; }
+    static __device__ __forceinline__ acc mfma(frag a, frag b, acc c)
+    {
+        return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ list empty() { return list{I8_EMPTY, I8_EMPTY, I8_EMPTY, I8_EMPTY}; }
+    static __device__ __forceinline__ int med3(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }
+    static __device__ __forceinline__ void select(const acc& a, unsigned par, unsigned gid, list& cl, int g)
+    {
+        const int m0 = max(max(a[8 * g], a[8 * g + 1]), a[8 * g + 2]);              // v_max3_i32 x3 + v_max_i32
+        const int m1 = max(max(a[8 * g + 3], a[8 * g + 4]), a[8 * g + 5]);
+        const int m = max(max(max(m0, m1), a[8 * g + 6]), a[8 * g + 7]);
+        const int x = static_cast<int>((static_cast<unsigned>(m) << I8_SHIFT) | gid);   // v_lshl_or_b32
+        (void)par;
+        insert(cl, x);
+    }
+    static __device__ __forceinline__ void insert(list& cl, int x)
+    {
+        const int n0 = max(x, cl[0]);
+        const int n1 = med3(x, cl[0], cl[1]);
+        const int n2 = med3(x, cl[1], cl[2]);
+        const int n3 = med3(x, cl[2], cl[3]);
+        cl[0] = n0; cl[1] = n1; cl[2] = n2; cl[3] = n3;
+    }
+    static __device__ __forceinline__ void merge(list& cl, int h)     // MERGE == false: only tags the ids with the half
+    {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cl[i] = cl[i] == I8_EMPTY ? I8_EMPTY : (cl[i] | h);
+    }
+};
+
+// a tile = 128 rows x R::ROW16 16-byte units, staged through registers by THREADS threads
+template <typename R, int THREADS>
+struct HTile {
+    static constexpr int TOTAL = H_TT * R::ROW16;
+    static constexpr int PIECES = (TOTAL + THREADS - 1) / THREADS;
+    static constexpr bool EVEN = TOTAL % THREADS == 0;
+    uint4 stg[PIECES];
+    __device__ __forceinline__ void load(const uint4* __restrict__ Th, int tile, int tid)
+    {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            int f = tid + THREADS * i;
+            if (!EVEN) f = f < TOTAL ? f : TOTAL - 1;          // clamped: the load stays unconditional
+            stg[i] = Th[static_cast<size_t>(tile) * TOTAL + f];  // rows are contiguous: piece f of the tile
+        }
+    }
+    __device__ __forceinline__ void store(uint4* __restrict__ hsm, int buf, int tid) const
+    {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int f = tid + THREADS * i;
+            const int row = f / R::ROW16, c8 = f % R::ROW16;
+            if (EVEN || f < TOTAL) hsm[(buf * H_TT + row) * R::LDS_ROW16 + c8] = stg[i];
+        }
+    }
+};
+
+// The same tile staged by LDS-DMA (global_load_lds_dwordx4: global -> LDS with no VGPR stop and no ds_write): the padded
+// LDS image of a tile is 128 x LDS_ROW16 sixteen-byte slots = a whole number of 1-KiB pieces (38 for the f16 route,
+// 34 for i8); one wave-instruction fills piece p, lane l writing slot 64p + l.  The destination is lane-linear, so the
+// row padding lives in the SOURCE address: slot s belongs to row s / LDS_ROW16, column s % LDS_ROW16, and the lane that
+// lands in a pad slot simply re-reads the row's last column (the pad is never read).  Per-lane source offsets are fixed
+// for the whole kernel (wave w owns pieces w, w + NW, ...).
+template <typename R, int THREADS>
+struct HTileDma {
+    static constexpr int NW = THREADS / 64;
+    static constexpr int SLOTS = H_TT * R::LDS_ROW16;
+    static_assert(SLOTS % 64 == 0, "the padded tile must be a whole number of 1-KiB pieces");
+    static constexpr int NPIECES = SLOTS / 64;
+    static constexpr int PER_WAVE = (NPIECES + NW - 1) / NW;
+    static constexpr int TOTAL = H_TT * R::ROW16;
+    unsigned src[PER_WAVE];                       // 16-byte units from the start of a tile in global memory
+    __device__ __forceinline__ void init(int lane, int wave)
+    {
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; ++i) {
+            const int p = wave + NW * i;
+            const int s = 64 * (p < NPIECES ? p : NPIECES - 1) + lane;
+            const int row = s / R::LDS_ROW16, c = s % R::LDS_ROW16;
+            src[i] = static_cast<unsigned>(row * R::ROW16 + (c < R::ROW16 ? c : R::ROW16 - 1));
+        }
+    }
+    __device__ __forceinline__ void issue(const uint4* __restrict__ Th, int tile, uint4* __restrict__ hsm, int buf, int wave) const
+    {
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; ++i) {
+            const int p = wave + NW * i;
+            if (p < NPIECES) {                     // wave-uniform
+                const uint4* g = Th + static_cast<size_t>(tile) * TOTAL + src[i];
+                uint4* l = hsm + buf * SLOTS + 64 * p;
+                typedef const __attribute__((address_space(1))) void* gptr_t;      // generic -> global / LDS address space
+                typedef __attribute__((address_space(3))) void* lptr_t;
+                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+            }
+        }
+    }
+};
+
+// one 32-row block of the tile: 9 k-chunks x NQB query blocks of MFMAs, selecting the previous
+// block's accumulators p[] (group-id base pbase) in between, from chunk 1 on (see knn_tile_compute).
+// tb: this lane's row in the LDS tile, in 16-byte units (chunk c = tb[2*c])
+template <typename R, int NQB, bool EPI, typename ABL>
+__device__ __forceinline__ void h_block(const uint4* __restrict__ tb, const typename R::frag (&qf)[NQB][R::NCH],
+                                        typename R::acc (&a)[NQB], const typename R::acc (&p)[NQB], unsigned pbase,
+                                        unsigned par, typename R::list (&cl)[NQB])
+{
+    typedef typename R::frag frag;
+    // A fragments run three chunks ahead of their use: one chunk is only 32*NQB pipe cycles, less
+    // than an LDS round trip
+    frag ring[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ring[c] = *reinterpret_cast<const frag*>(tb + 2 * c);
+#pragma unroll
+    for (int c = 0; c < R::NCH; ++c) {
+        const frag x = ring[c % 3];
+        if constexpr (!ABL::no_ldsread) {
+            if (c + 3 < R::NCH) ring[c % 3] = *reinterpret_cast<const frag*>(tb + 2 * (c + 3));
+        }
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) a[qb] = R::mfma(x, qf[qb][c], c == 0 ? R::zero() : a[qb]);
+        if constexpr (ABL::no_epi) {
+            if (EPI && c == 1) {                  // timing-only build: the accumulators stay live, nothing is selected
+#pragma unroll
+                for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(p[qb][e]));
+            }
+        }
+        if (EPI && c >= 1 && !ABL::no_epi) {      // GPB*NQB row groups spread over chunks 1..NCH-1
+            constexpr int NGB = R::GPB * NQB;
+#pragma unroll
+            for (int e = (c - 1) * NGB / (R::NCH - 1); e < c * NGB / (R::NCH - 1); ++e)   // query column e % NQB, group e / NQB
+                R::select(p[e % NQB], par, (pbase + static_cast<unsigned>(e / NQB)) << 1, cl[e % NQB], e / NQB);
+            if (NQB == 2)
+                asm volatile("" : "+v"(cl[0][0]), "+v"(cl[0][1]), "+v"(cl[0][2]), "+v"(cl[0][3]), "+v"(cl[NQB - 1][0]),
+                             "+v"(cl[NQB - 1][1]), "+v"(cl[NQB - 1][2]), "+v"(cl[NQB - 1][3]));
+            else
+                asm volatile("" : "+v"(cl[0][0]), "+v"(cl[0][1]), "+v"(cl[0][2]), "+v"(cl[0][3]));
+        }
+    }
+}
+
+// NQB query blocks (of 32) per wave: 2 -> 4 waves per workgroup, 2 waves per SIMD (each A fragment
+// feeds two MFMAs); 1 -> 8 waves per workgroup, 4 waves per SIMD at <= 128 VGPRs (more waves to
+// cover LDS / barrier / MFMA-dependency latency).  Either way a workgroup owns H_QB = 256 queries.
+// mode: 0 = run always (hint / i8), 1 = run only if prep16 found the data eligible (auto)
+template <typename R, int NQB, bool DMA, typename ABL>
+__global__ __launch_bounds__(H_QB / (32 * NQB) * 64, (NQB == 2 ? 2 : 4)) void knn_mfma_rows288(
+    const uint4* __restrict__ Qh, const uint4* __restrict__ Th, int nq, int nt, int tiles_per_split, unsigned par,
+    typename R::list* __restrict__ cand_val, int slots, const unsigned long long* __restrict__ stats, unsigned epoch,
+    int mode)
+{
+    typedef typename R::frag frag;
+    typedef typename R::acc acc;
+    typedef typename R::list list;
+    constexpr int THREADS = H_QB / (32 * NQB) * 64;
+    if (mode == 1) {
+        const unsigned long long s1 = stats[1];
+        if (static_cast<unsigned>(s1 >> 32) == epoch && (s1 & 2ull)) return;      // f32 route takes over
+    }
+    extern __shared__ __attribute__((aligned(16))) uint4 hsm[];                   // [2][H_TT][R::LDS_ROW16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int qbase = blockIdx.x * H_QB + wave * 32 * NQB;
+
+    // both global streams are requested before anything waits: the first train tile, then the query fragments
+    HTile<R, THREADS> st;
+    HTileDma<R, THREADS> dma;
+    const int ntiles = (nt + H_TT - 1) / H_TT;
+    const int tile0 = blockIdx.y * tiles_per_split;
+    if (DMA) {
+        dma.init(lane, wave);
+        dma.issue(Th, tile0 < ntiles ? tile0 : ntiles - 1, hsm, 0, wave);
+    } else {
+        st.load(Th, tile0 < ntiles ? tile0 : ntiles - 1, tid);      // unconditional (clamped): nt >= 1
+    }
+    frag qf[NQB][R::NCH];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+        for (int c = 0; c < R::NCH; ++c)
+            qf[qb][c] = *reinterpret_cast<const frag*>(Qh + static_cast<size_t>(qbase + 32 * qb + r) * R::ROW16 + 2 * c + h);
+    // make the fragments opaque: hipcc otherwise treats the loads as rematerialisable and re-reads
+    // some of them from global memory inside the tile loop
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+        for (int c = 0; c < R::NCH; ++c) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 t = __builtin_bit_cast(u32x4, qf[qb][c]);
+            asm volatile("" : "+v"(t));
+            qf[qb][c] = __builtin_bit_cast(frag, t);
+        }
+
+    int tile1 = tile0 + tiles_per_split;
+    if (tile1 > ntiles) tile1 = ntiles;
+    list cl[NQB];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) cl[qb] = R::empty();
+
+    if (tile0 < tile1) {
+        if (!DMA) st.store(hsm, 0, tid);
+        __syncthreads();                                        // (with DMA in flight the barrier's fence waits vmcnt(0))
+        acc A[NQB], B[NQB];
+        for (int tix = 0; tix < tile1 - tile0; ++tix) {
+            const int buf = tix & 1;
+            const uint4* tb = hsm + (buf * H_TT + r) * R::LDS_ROW16 + h;
+            constexpr unsigned G = R::GPB;
+            const unsigned lb = static_cast<unsigned>(tix) * (4u * G);     // group ids of this tile: lb + GPB*blk + g
+            // the last tile is simply staged again: past the end nothing reads the other buffer
+            if constexpr (!ABL::no_stage) {
+                // the other buffer was last read in tile tix - 1, and every wave has passed that tile's barrier
+                if (DMA) dma.issue(Th, tile0 + tix + 1 < ntiles ? tile0 + tix + 1 : tile0 + tix, hsm, buf ^ 1, wave);
+                else st.load(Th, tile0 + tix + 1 < ntiles ? tile0 + tix + 1 : tile0 + tix, tid);
+            }
+            if (tix == 0) h_block<R, NQB, false, ABL>(tb, qf, A, A, 0u, par, cl);
+            else h_block<R, NQB, true, ABL>(tb, qf, A, B, lb - G, par, cl);                         // B = block 3 of tile-1
+            h_block<R, NQB, true, ABL>(tb + 32 * R::LDS_ROW16, qf, B, A, lb, par, cl);
+            h_block<R, NQB, true, ABL>(tb + 64 * R::LDS_ROW16, qf, A, B, lb + G, par, cl);
+            if constexpr (!ABL::no_stage) {
+                if (!DMA) st.store(hsm, buf ^ 1, tid);
+            }
+            h_block<R, NQB, true, ABL>(tb + 96 * R::LDS_ROW16, qf, B, A, lb + 2u * G, par, cl);
+            tile_barrier<ABL>();
+        }
+        const unsigned lb = static_cast<unsigned>(tile1 - tile0 - 1) * (4u * R::GPB) + 3u * R::GPB;
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+            for (int g = 0; g < R::GPB; ++g) R::select(B[qb], par, (lb + static_cast<unsigned>(g)) << 1, cl[qb], g);
+    }
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+        const int q = qbase + 32 * qb + r;
+        R::merge(cl[qb], h);
+        if (R::MERGE) {
+            if (q < nq && h == 0) cand_val[(static_cast<size_t>(q) * slots + blockIdx.y * KNN_C) / KNN_C] = cl[qb];
+        } else {
+            if (q < nq) cand_val[(static_cast<size_t>(q) * slots + (blockIdx.y * 2 + h) * KNN_C) / KNN_C] = cl[qb];
+        }
+    }
+}
+
+template <int NCH, bool FULL, int TT, typename ABL>
+int launch_mfma(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt, int dim, const float* tnorm, int splits,
+                int tiles_per_split, unsigned keep_mask, float* cval, int slots, const unsigned long long* stats,
+                unsigned epoch, int only_if_ineligible)
+{
+    constexpr int LDT = NCH * 8 + 4;
+    const size_t lds = 2 * TT * LDT * sizeof(float);
+    static bool attr_done_dev[PM_MAX_DEVICES] = {};          // the attribute is per device (and per template instance)
+    bool& attr_done = attr_done_dev[ctx->device];
+    if (!attr_done) {
+        PM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_l2_mfma<NCH, FULL, TT, ABL>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        attr_done = true;
+    }
+    dim3 grid((nq + QB - 1) / QB, splits);
+    pm::ScopedKernelTime t(ctx, "knn_l2_mfma");
+    hipLaunchKernelGGL((knn_l2_mfma<NCH, FULL, TT, ABL>), grid, dim3(256), lds, ctx->stream, dq, dt, tnorm, nq, nt, dim,
+                       tiles_per_split, keep_mask, cval, slots, stats, epoch, only_if_ineligible);
+    PM_HIP_CHECK(hipGetLastError());
+    return PM_OK;
+}
+
+template <typename ABL>
+int coarse_f32_dispatch(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt, int dim, const float* tnorm,
+                      int splits, int tiles_per_split, unsigned keep_mask, float* cval, int slots,
+                      const unsigned long long* stats, unsigned epoch, int only_if_ineligible)
+{
+#define PM_LAUNCH_MFMA(NCH_, FULL_)                                                                              \
+    launch_mfma<NCH_, FULL_, TT32, ABL>(ctx, dq, nq, dt, nt, dim, tnorm, splits, tiles_per_split, keep_mask, cval, slots, \
+                                   stats, epoch, only_if_ineligible)
+    if (dim == 128) return PM_LAUNCH_MFMA(16, true);
+    if (dim == 64) return PM_LAUNCH_MFMA(8, true);
+    if (dim == 32) return PM_LAUNCH_MFMA(4, true);
+    if (dim < 32) return PM_LAUNCH_MFMA(4, false);
+    if (dim < 64) return PM_LAUNCH_MFMA(8, false);
+    return PM_LAUNCH_MFMA(16, false);
+#undef PM_LAUNCH_MFMA
+}
+
+template <typename R, typename ABL>
+int launch_rows288(pm_ctx* ctx, const char* name, const void* Qh, const void* Th, int nq, int nq_pad, int nt, int splits,
+                   int tiles_per_split, unsigned par, void* cval, int slots, const unsigned long long* stats,
+                   unsigned epoch, int mode)
+{
+    const size_t lds = sizeof(uint4) * 2 * H_TT * R::LDS_ROW16;
+    // few tiles per workgroup: the 8-wave form covers latency better; long sweeps: the 4-wave form halves LDS reads
+    const int nqb_opt = ctx->opts[PM_OPT_KNN_F16_WAVES];
+    const int nqb = nqb_opt ? nqb_opt : (tiles_per_split <= 8 ? 1 : 2);
+    static bool attr_done_dev[PM_MAX_DEVICES] = {};          // the attribute is per device (and per template instance)
+    bool& attr_done = attr_done_dev[ctx->device];
+    if (!attr_done) {
+#define PM_ATTR(NQB_, DMA_)                                                                                       \
+    PM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_mfma_rows288<R, NQB_, DMA_, ABL>),             \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)))
+        PM_ATTR(1, false); PM_ATTR(2, false); PM_ATTR(1, true); PM_ATTR(2, true);
+#undef PM_ATTR
+        attr_done = true;
+    }
+    pm::ScopedKernelTime t(ctx, name);
+    const uint4* q4 = static_cast<const uint4*>(Qh);
+    const uint4* t4 = static_cast<const uint4*>(Th);
+    typename R::list* out = static_cast<typename R::list*>(cval);
+    // train tiles by LDS-DMA unless pinned to register staging (measured: C3 f16 21.3 -> 19.3 us, 32k x 32k f16 233 -> 210 us,
+    // C4 i8 211 -> 198 us: the ds_write_b128 pass and 16 staging VGPRs disappear)
+    const bool dma = ctx->opts[PM_OPT_KNN_STAGING] != 1;
+#define PM_GO(NQB_, DMA_, THREADS_)                                                                                \
+    hipLaunchKernelGGL((knn_mfma_rows288<R, NQB_, DMA_, ABL>), dim3(nq_pad / H_QB, splits), dim3(THREADS_), lds, ctx->stream, q4, \
+                       t4, nq, nt, tiles_per_split, par, out, slots, stats, epoch, mode)
+    if (nqb == 2) { if (dma) PM_GO(2, true, 256); else PM_GO(2, false, 256); }
+    else { if (dma) PM_GO(1, true, 512); else PM_GO(1, false, 512); }
+#undef PM_GO
+    PM_HIP_CHECK(hipGetLastError());
+    return PM_OK;
+}
+
+}  // namespace
+}  // namespace pm_knn

@@ -9,9 +9,13 @@
 
 namespace pm_ransac {
 
-#ifndef PM_SOLVE_STAMP
-#define PM_SOLVE_STAMP(i) do { } while (0)       // diagnostic builds of ransac_fused.hip time the solver's phases
-#endif
+// Diagnostics policy of the RANSAC kernels.  The product instantiates everything with NoDiag (empty inline hooks,
+// no code); tools/ablation/ransac_fused_stamps.hip supplies a policy that writes shader-clock stamps.
+struct NoDiag {
+    static constexpr bool scalar_fma = false;                       // score with unpacked v_fma_f32 (experiment)
+    static __device__ __forceinline__ void phase(int) {}            // kernel phase boundary i
+    static __device__ __forceinline__ void solve(int) {}            // solver phase boundary i
+};
 
 constexpr int MODEL_STRIDE = 12;   // 9 x fp32 F, valid flag, 2 pad
 
@@ -133,6 +137,7 @@ __device__ __forceinline__ void jacobi_pair(double (&G)[3][3], double (&V)[3][3]
 }
 
 // SPEC S7: normalised 8-point solve.  Returns false for a degenerate sample (F is then 0).
+template <typename DIAG = NoDiag>
 __device__ __forceinline__ bool solve8(const double (&x1)[8], const double (&y1)[8], const double (&x2)[8],
                                     const double (&y2)[8], double (&F)[9])
 {
@@ -142,7 +147,7 @@ __device__ __forceinline__ bool solve8(const double (&x1)[8], const double (&y1)
     if (!hartley8(x1, y1, ax, ay, s1, t1x, t1y)) return false;
     if (!hartley8(x2, y2, bx, by, s2, t2x, t2y)) return false;
 
-    PM_SOLVE_STAMP(1);
+    DIAG::solve(1);
     // B = A^T (9 x 8): column c is the epipolar constraint row of correspondence c
     double B[9][8], beta[8];
 #pragma unroll
@@ -175,7 +180,7 @@ __device__ __forceinline__ bool solve8(const double (&x1)[8], const double (&y1)
             for (int i = j + 1; i < 9; ++i) B[i][c] = fma(-w, B[i][j], B[i][c]);
         }
     }
-    PM_SOLVE_STAMP(2);
+    DIAG::solve(2);
     // null vector f = H0 H1 ... H7 e8
     double f[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0};
 #pragma unroll
@@ -189,7 +194,7 @@ __device__ __forceinline__ bool solve8(const double (&x1)[8], const double (&y1)
 #pragma unroll
         for (int i = j + 1; i < 9; ++i) f[i] = fma(-w, B[i][j], f[i]);
     }
-    PM_SOLVE_STAMP(3);
+    DIAG::solve(3);
     // rank 2: one-sided Jacobi on the columns of G, six fixed sweeps, then drop the smallest column
     double G[3][3], V[3][3] = {{1.0, 0.0, 0.0}, {0.0, 1.0, 0.0}, {0.0, 0.0, 1.0}};
 #pragma unroll
@@ -201,7 +206,7 @@ __device__ __forceinline__ bool solve8(const double (&x1)[8], const double (&y1)
         jacobi_pair<0, 2>(G, V);
         jacobi_pair<1, 2>(G, V);
     }
-    PM_SOLVE_STAMP(4);
+    DIAG::solve(4);
     double cn[3];
 #pragma unroll
     for (int p = 0; p < 3; ++p) {

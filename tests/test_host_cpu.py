@@ -121,3 +121,19 @@ def test_header_is_plain_c(tmp_path):
     text = open(os.path.join(inc, "pm.h")).read()
     includes = [ln.strip() for ln in text.splitlines() if ln.strip().startswith("#include")]
     assert includes == ["#include <stddef.h>", "#include <stdint.h>"], includes
+
+
+def test_product_sources_carry_no_diagnostic_switches():
+    """The shipped kernels are instantiated with the no-op policies only: no preprocessor switch in csrc/ selects an
+    ablation or stamping build (those live in tools/ablation/*.hip), nothing reads the environment, and the library
+    exports no debug entry point."""
+    csrc = os.path.join(ROOT, "points_matching_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        text = open(os.path.join(csrc, f)).read()
+        conds = [ln.strip() for ln in text.splitlines() if re.match(r"\s*#\s*(if|ifdef|ifndef|elif)\b", ln)]
+        assert all(c == "#if defined(__HIPCC__)" for c in conds), (f, conds)
+        assert "getenv" not in text, f
+    r = __import__("subprocess").run(["nm", "-D", "--defined-only", api.LIB_PATH], capture_output=True, text=True)
+    assert r.returncode == 0
+    syms = [ln.split()[-1] for ln in r.stdout.splitlines() if ln.strip()]
+    assert not [s for s in syms if "debug" in s or "stamp" in s]

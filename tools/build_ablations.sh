@@ -1,16 +1,20 @@
 #!/bin/bash
 # Timing-only variants of the coarse kNN kernels (outputs are wrong): which part of a tile costs what.
-# PM_ABL_NOEPI drops the in-chain selection (both the f32 kernel and the 288/256-byte-row kernel);
-# NOSTAGE / NOBARRIER / NOLDSREAD apply to the f32 kernel.  Use with PM_LIB_PATH=<variant .so>.
+# Each variant library = the product objects with knn_coarse.o swapped for tools/ablation/knn_coarse_ablation.hip
+# compiled with one policy.  Use with PM_LIB_PATH=<variant .so>.  NO_EPI applies to every coarse kernel;
+# NO_STAGE / NO_BARRIER / NO_LDSREAD to the f32 kernel.
 set -e
 cd "$(dirname "$0")/.."
 python -m points_matching_amd.build > /dev/null
-mkdir -p points_matching_amd/build/abl
-F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -ffinite-math-only -Iinclude -Ipoints_matching_amd/csrc"
 B=points_matching_amd/build
-for v in BASE NOEPI NOSTAGE NOBARRIER NOLDSREAD "NOEPI -DPM_ABL_NOSTAGE" "NOEPI -DPM_ABL_NOSTAGE -DPM_ABL_NOBARRIER" "NOEPI -DPM_ABL_NOSTAGE -DPM_ABL_NOBARRIER -DPM_ABL_NOLDSREAD"; do
-  name=$(echo "$v" | sed 's/ -DPM_ABL_/_/g')
-  /opt/rocm/bin/hipcc $F -DPM_ABL_$v -x hip -c points_matching_amd/csrc/knn_coarse.hip -o /tmp/abl_coarse.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $B/abl/libpm_$name.so /tmp/abl_coarse.o $B/pm_capi.o $B/knn_l2.o $B/knn_hamming.o $B/ransac.o $B/filter_gather.o $B/pair_batch.o $B/lmeds.o
+mkdir -p $B/abl
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -ffinite-math-only -Iinclude -Ipoints_matching_amd/csrc -I/opt/rocm/include"
+OBJS=$(ls $B/*.o | grep -v '/knn_coarse\.o$')
+for v in BASE "NO_EPI" "NO_STAGE" "NO_BARRIER" "NO_LDSREAD" "NO_EPI NO_STAGE" "NO_EPI NO_STAGE NO_BARRIER" "NO_EPI NO_STAGE NO_BARRIER NO_LDSREAD"; do
+  name=$(echo "$v" | tr -d '_' | tr ' ' '_')
+  defs=""
+  if [ "$v" != BASE ]; then for w in $v; do defs="$defs -DABL_$w=1"; done; fi
+  /opt/rocm/bin/hipcc $F $defs -x hip -c tools/ablation/knn_coarse_ablation.hip -o /tmp/abl_coarse.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $B/abl/libpm_$name.so /tmp/abl_coarse.o $OBJS -ldl
   echo built $name
 done
