@@ -84,7 +84,8 @@ enum {
     PM_OPT_RANSAC_PATH    = 1,  /* 1: hypothesis-per-lane kernels (solve + score launches), 2: one-launch kernel  */
     PM_OPT_SCORE_OPERANDS = 2,  /* hypothesis-per-lane scorer: 1 LDS-staged points, 2 scalar-operand pair records */
     PM_OPT_HAMMING_ROUTE  = 3,  /* 1: integer-VALU scan, 2: matrix-core route with 64-bit refinement keys          */
-    PM_OPT_KNN_F16_WAVES  = 4,  /* f16/i8 coarse kernel: 1 = 8 waves x 32 queries, 2 = 4 waves x 64 queries        */
+    PM_OPT_KNN_F16_WAVES  = 4,  /* f16/i8 coarse kernel: 1 = 8 waves x 32 queries, 2 = 4 waves x 64 queries,
+                                   3 (f16 only) = 8 waves x 64 queries in two row groups                         */
     PM_OPT_KNN_STAGING    = 6,  /* f16/i8 coarse kernel, train tiles: 1 = through registers, 2 = LDS-DMA (default)  */
     PM_OPT_KNN_WG_PER_CU  = 7,  /* f16 coarse kernel: train splits sized for 1 (default) or 2 workgroups per CU     */
     PM_OPT_FILTER_FUSION  = 5,  /* pm_bf_knn_l2_ratio_dev: 1 = filter as its own launch, 2 = inside the refinement  */

@@ -342,6 +342,7 @@ struct RouteF16 {
         top4_insert(cl, embed_lid(group_max(a, g), par, gid));
     }
     static __device__ __forceinline__ void merge(list& cl, int h) { merge_halves(cl, h); }
+    static __device__ __forceinline__ void put(list& cl, float x) { top4_insert(cl, x); }
 };
 
 struct RouteI8 {
@@ -370,6 +371,7 @@ struct RouteI8 {
         (void)par;
         insert(cl, x);
     }
+    static __device__ __forceinline__ void put(list& cl, int x) { insert(cl, x); }
     static __device__ __forceinline__ void insert(list& cl, int x)
     {
         const int n0 = max(x, cl[0]);
@@ -437,17 +439,20 @@ struct HTileDma {
             src[i] = static_cast<unsigned>(row * R::ROW16 + (c < R::ROW16 ? c : R::ROW16 - 1));
         }
     }
-    __device__ __forceinline__ void issue(const uint4* __restrict__ Th, int tile, uint4* __restrict__ hsm, int buf, int wave) const
+    // MUBUF form (buffer_load_dwordx4 ... offen lds), not global_load_lds: hipcc files the FLAT-encoded LDS-DMA as a
+    // pending FLAT access and from then on waits lgkmcnt(0) before every LDS operand use — the A-fragment ring (three
+    // ds_read_b128 ahead) collapsed to one exposed LDS round trip per MFMA.  A buffer load only counts on vmcnt.
+    // rsrc: the padded f16/i8 train copy (whole tiles), built from wave-uniform values; per-lane part = voffset.
+    __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rsrc, int tile, uint4* __restrict__ hsm, int buf, int wave) const
     {
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        const int soff = tile * (TOTAL * 16);                // wave-uniform byte offset of the tile (< 2^31: checked on the host)
 #pragma unroll
         for (int i = 0; i < PER_WAVE; ++i) {
             const int p = wave + NW * i;
             if (p < NPIECES) {                     // wave-uniform
-                const uint4* g = Th + static_cast<size_t>(tile) * TOTAL + src[i];
                 uint4* l = hsm + buf * SLOTS + 64 * p;
-                typedef const __attribute__((address_space(1))) void* gptr_t;      // generic -> global / LDS address space
-                typedef __attribute__((address_space(3))) void* lptr_t;
-                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)l, 16, static_cast<int>(src[i]) * 16, soff, 0, 0);
             }
         }
     }
@@ -500,9 +505,14 @@ __device__ __forceinline__ void h_block(const uint4* __restrict__ tb, const type
 // NQB query blocks (of 32) per wave: 2 -> 4 waves per workgroup, 2 waves per SIMD (each A fragment
 // feeds two MFMAs); 1 -> 8 waves per workgroup, 4 waves per SIMD at <= 128 VGPRs (more waves to
 // cover LDS / barrier / MFMA-dependency latency).  Either way a workgroup owns H_QB = 256 queries.
+// GR = 2 (with NQB = 2): TWO groups of four waves own the same 256 queries and split every tile's rows between them
+// (group g takes the 32-row blocks 2g, 2g+1): 8 waves = 2 per SIMD in ONE workgroup per CU, every A fragment still
+// feeds two MFMAs (half the LDS operand reads of the NQB = 1 form, which are what bounds it: 1 KiB per MFMA at
+// 128 B/clk is exactly the matrix pipe's time), and the two groups' lists meet in LDS once, at the end — the split
+// count (and with it the refinement's input) stays that of one workgroup per CU.
 // mode: 0 = run always (hint / i8), 1 = run only if prep16 found the data eligible (auto)
-template <typename R, int NQB, bool DMA, typename ABL>
-__global__ __launch_bounds__(H_QB / (32 * NQB) * 64, (NQB == 2 ? 2 : 4)) void knn_mfma_rows288(
+template <typename R, int NQB, bool DMA, int GR, typename ABL>
+__global__ __launch_bounds__(H_QB / (32 * NQB) * 64 * GR, (NQB == 2 ? 2 : 4)) void knn_mfma_rows288(
     const uint4* __restrict__ Qh, const uint4* __restrict__ Th, int nq, int nt, int tiles_per_split, unsigned par,
     typename R::list* __restrict__ cand_val, int slots, const unsigned long long* __restrict__ stats, unsigned epoch,
     int mode)
@@ -510,7 +520,9 @@ __global__ __launch_bounds__(H_QB / (32 * NQB) * 64, (NQB == 2 ? 2 : 4)) void kn
     typedef typename R::frag frag;
     typedef typename R::acc acc;
     typedef typename R::list list;
-    constexpr int THREADS = H_QB / (32 * NQB) * 64;
+    constexpr int WPG = H_QB / (32 * NQB);                 // waves per row group
+    constexpr int THREADS = WPG * 64 * GR;
+    static_assert(GR == 1 || (GR == 2 && NQB == 2 && R::MERGE), "row groups: the 64-query form of a merged-list route");
     if (mode == 1) {
         const unsigned long long s1 = stats[1];
         if (static_cast<unsigned>(s1 >> 32) == epoch && (s1 & 2ull)) return;      // f32 route takes over
@@ -518,16 +530,19 @@ __global__ __launch_bounds__(H_QB / (32 * NQB) * 64, (NQB == 2 ? 2 : 4)) void kn
     extern __shared__ __attribute__((aligned(16))) uint4 hsm[];                   // [2][H_TT][R::LDS_ROW16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int qbase = blockIdx.x * H_QB + wave * 32 * NQB;
+    const int gw = wave % WPG, grp = wave / WPG;           // wave inside its row group, row group
+    const int qbase = blockIdx.x * H_QB + gw * 32 * NQB;
 
     // both global streams are requested before anything waits: the first train tile, then the query fragments
     HTile<R, THREADS> st;
     HTileDma<R, THREADS> dma;
     const int ntiles = (nt + H_TT - 1) / H_TT;
     const int tile0 = blockIdx.y * tiles_per_split;
+    const __amdgpu_buffer_rsrc_t t_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4*>(Th), 0, ntiles * (H_TT * R::ROW16 * 16), 0x00020000);
     if (DMA) {
         dma.init(lane, wave);
-        dma.issue(Th, tile0 < ntiles ? tile0 : ntiles - 1, hsm, 0, wave);
+        dma.issue(t_rsrc, tile0 < ntiles ? tile0 : ntiles - 1, hsm, 0, wave);
     } else {
         st.load(Th, tile0 < ntiles ? tile0 : ntiles - 1, tid);      // unconditional (clamped): nt >= 1
     }
@@ -567,24 +582,58 @@ __global__ __launch_bounds__(H_QB / (32 * NQB) * 64, (NQB == 2 ? 2 : 4)) void kn
             // the last tile is simply staged again: past the end nothing reads the other buffer
             if constexpr (!ABL::no_stage) {
                 // the other buffer was last read in tile tix - 1, and every wave has passed that tile's barrier
-                if (DMA) dma.issue(Th, tile0 + tix + 1 < ntiles ? tile0 + tix + 1 : tile0 + tix, hsm, buf ^ 1, wave);
+                if (DMA) dma.issue(t_rsrc, tile0 + tix + 1 < ntiles ? tile0 + tix + 1 : tile0 + tix, hsm, buf ^ 1, wave);
                 else st.load(Th, tile0 + tix + 1 < ntiles ? tile0 + tix + 1 : tile0 + tix, tid);
             }
-            if (tix == 0) h_block<R, NQB, false, ABL>(tb, qf, A, A, 0u, par, cl);
-            else h_block<R, NQB, true, ABL>(tb, qf, A, B, lb - G, par, cl);                         // B = block 3 of tile-1
-            h_block<R, NQB, true, ABL>(tb + 32 * R::LDS_ROW16, qf, B, A, lb, par, cl);
-            h_block<R, NQB, true, ABL>(tb + 64 * R::LDS_ROW16, qf, A, B, lb + G, par, cl);
-            if constexpr (!ABL::no_stage) {
-                if (!DMA) st.store(hsm, buf ^ 1, tid);
+            if constexpr (GR == 1) {
+                if (tix == 0) h_block<R, NQB, false, ABL>(tb, qf, A, A, 0u, par, cl);
+                else h_block<R, NQB, true, ABL>(tb, qf, A, B, lb - G, par, cl);                     // B = block 3 of tile-1
+                h_block<R, NQB, true, ABL>(tb + 32 * R::LDS_ROW16, qf, B, A, lb, par, cl);
+                h_block<R, NQB, true, ABL>(tb + 64 * R::LDS_ROW16, qf, A, B, lb + G, par, cl);
+                if constexpr (!ABL::no_stage) {
+                    if (!DMA) st.store(hsm, buf ^ 1, tid);
+                }
+                h_block<R, NQB, true, ABL>(tb + 96 * R::LDS_ROW16, qf, B, A, lb + 2u * G, par, cl);
+            } else {
+                // this group's blocks 2*grp and 2*grp + 1 of the tile (group ids lb + G*block + g, as above)
+                const uint4* tg = tb + grp * 64 * R::LDS_ROW16;
+                const unsigned gb = lb + 2u * static_cast<unsigned>(grp) * G;
+                if (tix == 0) h_block<R, NQB, false, ABL>(tg, qf, A, A, 0u, par, cl);
+                else h_block<R, NQB, true, ABL>(tg, qf, A, B, gb - 3u * G, par, cl);                // B = block 2*grp+1 of tile-1
+                if constexpr (!ABL::no_stage) {
+                    if (!DMA) st.store(hsm, buf ^ 1, tid);
+                }
+                h_block<R, NQB, true, ABL>(tg + 32 * R::LDS_ROW16, qf, B, A, gb, par, cl);
             }
-            h_block<R, NQB, true, ABL>(tb + 96 * R::LDS_ROW16, qf, B, A, lb + 2u * G, par, cl);
             tile_barrier<ABL>();
         }
-        const unsigned lb = static_cast<unsigned>(tile1 - tile0 - 1) * (4u * R::GPB) + 3u * R::GPB;
+        const unsigned lb = static_cast<unsigned>(tile1 - tile0 - 1) * (4u * R::GPB) +
+                            (GR == 1 ? 3u : 2u * static_cast<unsigned>(grp) + 1u) * R::GPB;
 #pragma unroll
         for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
             for (int g = 0; g < R::GPB; ++g) R::select(B[qb], par, (lb + static_cast<unsigned>(g)) << 1, cl[qb], g);
+    }
+    if constexpr (GR == 2) {
+        // the two row groups' lists of a query meet in LDS (the tile buffers are idle: every wave is past the last
+        // tile's barrier, whose fence also drained the LDS-DMA)
+        list* xs = reinterpret_cast<list*>(hsm);
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) {
+            R::merge(cl[qb], h);
+            if (grp == 1) xs[(gw * NQB + qb) * 64 + lane] = cl[qb];
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) {
+            const list o = xs[(gw * NQB + qb) * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) R::put(cl[qb], o[i]);
+            const int q = qbase + 32 * qb + r;
+            if (q < nq && h == 0) cand_val[(static_cast<size_t>(q) * slots + blockIdx.y * KNN_C) / KNN_C] = cl[qb];
+        }
+        return;
     }
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
@@ -645,14 +694,15 @@ int launch_rows288(pm_ctx* ctx, const char* name, const void* Qh, const void* Th
     const size_t lds = sizeof(uint4) * 2 * H_TT * R::LDS_ROW16;
     // few tiles per workgroup: the 8-wave form covers latency better; long sweeps: the 4-wave form halves LDS reads
     const int nqb_opt = ctx->opts[PM_OPT_KNN_F16_WAVES];
-    const int nqb = nqb_opt ? nqb_opt : (tiles_per_split <= 8 ? 1 : 2);
+    const int nqb = nqb_opt ? nqb_opt : (tiles_per_split <= 8 ? 1 : 2);          // 3: two row groups of 4 waves x 64 queries
     static bool attr_done_dev[PM_MAX_DEVICES] = {};          // the attribute is per device (and per template instance)
     bool& attr_done = attr_done_dev[ctx->device];
     if (!attr_done) {
-#define PM_ATTR(NQB_, DMA_)                                                                                       \
-    PM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_mfma_rows288<R, NQB_, DMA_, ABL>),             \
+#define PM_ATTR(NQB_, DMA_, GR_)                                                                                  \
+    PM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_mfma_rows288<R, NQB_, DMA_, GR_, ABL>),        \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)))
-        PM_ATTR(1, false); PM_ATTR(2, false); PM_ATTR(1, true); PM_ATTR(2, true);
+        PM_ATTR(1, false, 1); PM_ATTR(2, false, 1); PM_ATTR(1, true, 1); PM_ATTR(2, true, 1);
+        if constexpr (R::MERGE) { PM_ATTR(2, false, 2); PM_ATTR(2, true, 2); }
 #undef PM_ATTR
         attr_done = true;
     }
@@ -662,12 +712,22 @@ int launch_rows288(pm_ctx* ctx, const char* name, const void* Qh, const void* Th
     typename R::list* out = static_cast<typename R::list*>(cval);
     // train tiles by LDS-DMA unless pinned to register staging (measured: C3 f16 21.3 -> 19.3 us, 32k x 32k f16 233 -> 210 us,
     // C4 i8 211 -> 198 us: the ds_write_b128 pass and 16 staging VGPRs disappear)
-    const bool dma = ctx->opts[PM_OPT_KNN_STAGING] != 1;
-#define PM_GO(NQB_, DMA_, THREADS_)                                                                                \
-    hipLaunchKernelGGL((knn_mfma_rows288<R, NQB_, DMA_, ABL>), dim3(nq_pad / H_QB, splits), dim3(THREADS_), lds, ctx->stream, q4, \
-                       t4, nq, nt, tiles_per_split, par, out, slots, stats, epoch, mode)
-    if (nqb == 2) { if (dma) PM_GO(2, true, 256); else PM_GO(2, false, 256); }
-    else { if (dma) PM_GO(1, true, 512); else PM_GO(1, false, 512); }
+    // (the DMA form addresses the train copy through a buffer descriptor with 32-bit byte offsets: below 2 GiB only)
+    const bool dma = ctx->opts[PM_OPT_KNN_STAGING] != 1 &&
+                     (static_cast<long long>(nt) + H_TT) * (R::ROW16 * 16) < 0x7FFFFFFFLL;
+#define PM_GO(NQB_, DMA_, GR_, THREADS_)                                                                           \
+    hipLaunchKernelGGL((knn_mfma_rows288<R, NQB_, DMA_, GR_, ABL>), dim3(nq_pad / H_QB, splits), dim3(THREADS_), lds,  \
+                       ctx->stream, q4, t4, nq, nt, tiles_per_split, par, out, slots, stats, epoch, mode)
+    bool grouped = false;
+    if constexpr (R::MERGE) {
+        if (nqb == 3) {
+            grouped = true;
+            if (dma) PM_GO(2, true, 2, 512); else PM_GO(2, false, 2, 512);
+        }
+    }
+    if (grouped) { }
+    else if (nqb == 2) { if (dma) PM_GO(2, true, 1, 256); else PM_GO(2, false, 1, 256); }
+    else { if (dma) PM_GO(1, true, 1, 512); else PM_GO(1, false, 1, 512); }
 #undef PM_GO
     PM_HIP_CHECK(hipGetLastError());
     return PM_OK;

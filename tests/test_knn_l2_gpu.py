@@ -229,15 +229,23 @@ def test_lds_dma_staging_same_result(ctx, oracle, nq, nt):
     """PM_OPT_KNN_STAGING: the train tiles of the f16 coarse kernel go global -> LDS by LDS-DMA (2, the default: padded
     rows through the per-lane source address) or through registers (1); same candidates, same result."""
     w = synth.pair_workload(nq, nt, 128, seed=nq ^ nt, planted=0.4, kind="sift")
+    ctx.knn_diag_enable(True)
     base = ctx.bf_knn_l2(w["q"], w["t"], 2, pm.api.PM_KNN_HINT_INTEGER)
+    base_rescans = ctx.knn_stats()["rescans"]
+    assert base_rescans <= 1
     try:
         for staging in (1, 2):
             ctx.set_option(pm.api.PM_OPT_KNN_STAGING, staging)
-            for waves in (0, 1, 2):
+            for waves in (0, 1, 2, 3):           # 3: two row groups of 4 waves x 64 queries, lists merged in LDS
                 ctx.set_option(pm.api.PM_OPT_KNN_F16_WAVES, waves)
-                assert_matches_equal(ctx.bf_knn_l2(w["q"], w["t"], 2, pm.api.PM_KNN_HINT_INTEGER), base,
-                                     "staging %d, waves %d" % (staging, waves))
+                ctx.knn_diag_enable(True)
+                got = ctx.bf_knn_l2(w["q"], w["t"], 2, pm.api.PM_KNN_HINT_INTEGER)
+                st = ctx.knn_stats()
+                assert_matches_equal(got, base, "staging %d, waves %d" % (staging, waves))
+                # a wrong candidate id or a lost list would show as a re-scan (the refinement repairs it silently)
+                assert st["rescans"] == base_rescans and st["nonfinite"] == 0, (staging, waves, st)
     finally:
+        ctx.knn_diag_enable(False)
         ctx.set_option(pm.api.PM_OPT_KNN_STAGING, 0)
         ctx.set_option(pm.api.PM_OPT_KNN_F16_WAVES, 0)
     assert_matches_equal(base[:128], oracle.bf_knn_l2(w["q"][:128], w["t"], 2, nthreads=8), "vs oracle")
