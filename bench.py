@@ -333,15 +333,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The contract-timed region: exactly K steps, nothing but the path's own launches on the stream.  (Event records
+    # between the stages are not free on this hardware — each is a barrier packet that ends the overlap of one kernel's
+    # launch with its predecessor's tail; three per step cost ~14 us of a 65 us step — so the stage split is taken in
+    # a second pass of the same K steps, and `value`, the matcher stage's rate, comes from that instrumented pass:
+    # the conservative one of the two.)
     for _ in range(args.warmup):
         step()
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(ev[i])
+        step()
     fence()
     t1 = time.perf_counter()
     wall = t1 - t0
+    for i in range(args.steps):
+        step(ev[i])
+    fence()
     match_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     rest_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
     if multi:
@@ -493,7 +501,9 @@ def main():
                                   "Hamming" if hamming else "L2", H), "descriptors": args.kind, "k": K,
                    "coarse_route": "n/a (Hamming)" if hamming else
                                    "f16-MFMA (integer hint, device-verified)" if knn_flags else "auto"},
-        "stage_ms": {"match": match_ms, "ransac_and_exchange": rest_ms},
+        "stage_ms": {"match": match_ms, "ransac_and_exchange": rest_ms,
+                     "note": "hipEvent brackets in a second pass of the same K steps (the events themselves add "
+                             "~4-5 us per bracket); ms_per_step is the un-instrumented pass"},
         "ransac": {"hyp_per_s": hyp_per_s, "hypotheses": H, "n_matches": n_m, "inliers": n_inl,
                    "best_hyp": pm.api.ransac_key_hyp(key) if key else None},
         "kernels_us": kern, "knn_refine": kstats, "parity": parity,

@@ -249,3 +249,37 @@ def test_lds_dma_staging_same_result(ctx, oracle, nq, nt):
         ctx.set_option(pm.api.PM_OPT_KNN_STAGING, 0)
         ctx.set_option(pm.api.PM_OPT_KNN_F16_WAVES, 0)
     assert_matches_equal(base[:128], oracle.bf_knn_l2(w["q"][:128], w["t"], 2, nthreads=8), "vs oracle")
+
+
+def test_knn_l2_randomised(ctx, oracle):
+    """Seeded sweep over shapes, descriptor kinds, route flags and adversarial content: duplicated rows (exact ties),
+    rows that break the integer hint (fractions, negatives, values beyond the f16-exact range), widely scaled rows.
+    Every route must return the canonical result bit for bit."""
+    rng = np.random.default_rng(0xBEEF)
+    for case in range(28):
+        dim = int(rng.choice([4, 8, 16, 32, 64, 96, 128, 128, 128]))
+        nq = int(rng.integers(1, 2500))
+        nt = int(rng.integers(1, 6000))
+        k = int(rng.choice([1, 2]))
+        kind = str(rng.choice(["sift", "surf"]))
+        q, t, _ = (synth.sift_like if kind == "sift" else synth.surf_like)(nq, nt, dim, seed=500 + case)
+        twist = int(rng.integers(0, 5))
+        if twist == 1 and nt > 8:                       # runs of identical train rows, one of them a query's exact match
+            for _ in range(4):
+                a = int(rng.integers(0, nt)); ln = int(rng.integers(2, min(12, nt)))
+                b = int(rng.integers(0, nt - ln + 1))
+                t[b:b + ln] = t[a]
+                q[int(rng.integers(0, nq))] = t[a]
+        elif twist == 2:                                # break the integer premise in a few places
+            t[int(rng.integers(0, nt)), int(rng.integers(0, dim))] += 0.5
+            q[int(rng.integers(0, nq)), int(rng.integers(0, dim))] = -3.0
+        elif twist == 3:                                # beyond the range where f16 products stay exact
+            t[int(rng.integers(0, nt))] *= 7.0
+            q[int(rng.integers(0, nq))] *= 1000.0
+        elif twist == 4:                                # mixed scales
+            t[::3] *= np.float32(1e-3)
+            q[::2] *= np.float32(37.0)
+        want = oracle.bf_knn_l2(q, t, k, nthreads=8)
+        for flags in (0, PM_KNN_HINT_INTEGER, PM_KNN_FORCE_F32, PM_KNN_FORCE_EXACT):
+            assert_matches_equal(ctx.bf_knn_l2(q, t, k, flags), want,
+                                 "case %d: %s %dx%dx%d k=%d twist=%d flags=%d" % (case, kind, nq, nt, dim, k, twist, flags))

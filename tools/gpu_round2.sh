@@ -25,6 +25,8 @@ step bench_surf 300 bash -c "python bench.py --kind surf --no-cpu-baseline > $O/
 step bench_x1 300 bash -c "python bench.py --exercise-exchange --no-cpu-baseline > $O/bench_c3_exchange_world1.json 2> $O/bench_c3_exchange_world1.err"
 step bench_w2 300 bash -c "python bench.py --gpus 2 --backend gloo --single-device --steps 5 --warmup 2 --no-cpu-baseline --sustain-seconds 0 > $O/bench_c3_world2_gloo.json 2> $O/bench_c3_world2_gloo.err"
 step bench_w2s 300 bash -c "python bench.py --gpus 2 --backend gloo --single-device --workload c4 --scaling strong --steps 5 --warmup 2 --no-cpu-baseline --sustain-seconds 0 > $O/bench_c4_strong_world2_gloo.json 2> $O/bench_c4_strong_world2_gloo.err"
+step fallback 300 bash -c "python tools/fallback_perf.py > $O/fallback_perf.json 2> $O/fallback_perf.err"
+step h2d 200 bash -c "python tools/h2d_ceiling.py > $O/h2d_ceiling.txt 2>&1"
 cd /tmp && export TMPDIR=/tmp
 step trace_c3 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c3 -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-verify --sustain-seconds 0 > $O/trace_c3.log 2>&1
 step trace_c4 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c4 -- python3 $R/bench.py --workload c4 --steps 10 --warmup 3 --no-cpu-baseline --no-verify --sustain-seconds 0 > $O/trace_c4.log 2>&1
