@@ -26,6 +26,25 @@ struct Abl {
 };
 typedef Abl<false, false, false, false> AblNone;
 
+// Workgroup -> (query block, train split).  Workgroups are dispatched round-robin over the 8 XCDs in launch order (x
+// fastest), and every XCD has its own L2: in launch order each XCD ends up pulling ALL train splits (or all query
+// blocks) through its L2 — 8 x the train copy per launch.  When the grid allows it, XCD x owns a 2-D tile of the
+// grid instead: a quarter of the query blocks x half of the splits, i.e. Q/4 + T/2 through each L2 (the minimum of
+// 8 * (Q/a + T/b) over a*b = 8 for Q = T).  Measured (profiles/r02_pmc_*): C3 f16 fetch 21.3 -> 14.4 MB at unchanged
+// time.  Grids of several rounds keep the launch order (`tiled` = 0, chosen by the launcher): there the tile order put
+// 32 workgroups on one train stream at a time and cost time — 32k x 32k f16 205-211 -> 226-235 us, C4 i8 +3 % —
+// for the same 1/3 of traffic that the 256 MiB Infinity Cache absorbs anyway.
+struct WgTile { int qb, split; };
+__device__ __forceinline__ WgTile wg_tile(bool tiled)
+{
+    const int nx = gridDim.x, ny = gridDim.y;
+    if (!tiled || (nx & 3) || (ny & 1)) return WgTile{static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y)};
+    const int L = blockIdx.y * nx + blockIdx.x;
+    const int x = L & 7, j = L >> 3;                    // XCD, index inside the XCD
+    const int tw = nx >> 2, th = ny >> 1;               // the XCD's tile: tw query blocks x th splits
+    return WgTile{(x & 3) * tw + j % tw, (x >> 2) * th + j / tw};
+}
+
 template <typename ABL>
 __device__ __forceinline__ void tile_barrier()
 {
@@ -231,7 +250,7 @@ __global__ __launch_bounds__(256, (TT == 64 ? 2 : 1)) void knn_l2_mfma(
     int nt, int dim, int tiles_per_split, unsigned keep_mask, float* __restrict__ cand_val, int slots,
     const unsigned long long* __restrict__ stats, unsigned epoch, int only_if_ineligible)
 {
-    if (only_if_ineligible) {                  // auto mode: the f16 route handles eligible data
+    if (only_if_ineligible & 1) {              // auto mode: the f16 route handles eligible data (bit 1: XCD-tiled grid)
         const unsigned long long s1 = stats[1];
         if (!(static_cast<unsigned>(s1 >> 32) == epoch && (s1 & 2ull))) return;
     }
@@ -245,7 +264,8 @@ __global__ __launch_bounds__(256, (TT == 64 ? 2 : 1)) void knn_l2_mfma(
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int qrow = blockIdx.x * QB + wave * 32 + r;
+    const WgTile wg = wg_tile((only_if_ineligible & 2) != 0);
+    const int qrow = wg.qb * QB + wave * 32 + r;
     const int qld = qrow < nq ? qrow : nq - 1;
 
     // B operand: this lane's query row, k = 8c + 4h + {0..3} for chunk c (the k permutation is
@@ -262,7 +282,7 @@ __global__ __launch_bounds__(256, (TT == 64 ? 2 : 1)) void knn_l2_mfma(
     }
 
     const int ntiles = (nt + TT - 1) / TT;
-    const int tile0 = blockIdx.y * tiles_per_split;
+    const int tile0 = wg.split * tiles_per_split;
     int tile1 = tile0 + tiles_per_split;
     if (tile1 > ntiles) tile1 = ntiles;
 
@@ -299,7 +319,7 @@ __global__ __launch_bounds__(256, (TT == 64 ? 2 : 1)) void knn_l2_mfma(
 
     merge_halves(cl, h);
     if (qrow < nq && h == 0) {
-        const size_t o = static_cast<size_t>(qrow) * slots + blockIdx.y * KNN_C;
+        const size_t o = static_cast<size_t>(qrow) * slots + wg.split * KNN_C;
         *reinterpret_cast<f32x4*>(cand_val + o) = cl;
     }
 }
@@ -510,7 +530,7 @@ __device__ __forceinline__ void h_block(const uint4* __restrict__ tb, const type
 // feeds two MFMAs (half the LDS operand reads of the NQB = 1 form, which are what bounds it: 1 KiB per MFMA at
 // 128 B/clk is exactly the matrix pipe's time), and the two groups' lists meet in LDS once, at the end — the split
 // count (and with it the refinement's input) stays that of one workgroup per CU.
-// mode: 0 = run always (hint / i8), 1 = run only if prep16 found the data eligible (auto)
+// mode bit 0: 0 = run always (hint / i8), 1 = run only if prep16 found the data eligible (auto); bit 1: XCD-tiled grid
 template <typename R, int NQB, bool DMA, int GR, typename ABL>
 __global__ __launch_bounds__(H_QB / (32 * NQB) * 64 * GR, (NQB == 2 ? 2 : 4)) void knn_mfma_rows288(
     const uint4* __restrict__ Qh, const uint4* __restrict__ Th, int nq, int nt, int tiles_per_split, unsigned par,
@@ -523,7 +543,7 @@ __global__ __launch_bounds__(H_QB / (32 * NQB) * 64 * GR, (NQB == 2 ? 2 : 4)) vo
     constexpr int WPG = H_QB / (32 * NQB);                 // waves per row group
     constexpr int THREADS = WPG * 64 * GR;
     static_assert(GR == 1 || (GR == 2 && NQB == 2 && R::MERGE), "row groups: the 64-query form of a merged-list route");
-    if (mode == 1) {
+    if (mode & 1) {
         const unsigned long long s1 = stats[1];
         if (static_cast<unsigned>(s1 >> 32) == epoch && (s1 & 2ull)) return;      // f32 route takes over
     }
@@ -531,13 +551,14 @@ __global__ __launch_bounds__(H_QB / (32 * NQB) * 64 * GR, (NQB == 2 ? 2 : 4)) vo
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int gw = wave % WPG, grp = wave / WPG;           // wave inside its row group, row group
-    const int qbase = blockIdx.x * H_QB + gw * 32 * NQB;
+    const WgTile wg = wg_tile((mode & 2) != 0);
+    const int qbase = wg.qb * H_QB + gw * 32 * NQB;
 
     // both global streams are requested before anything waits: the first train tile, then the query fragments
     HTile<R, THREADS> st;
     HTileDma<R, THREADS> dma;
     const int ntiles = (nt + H_TT - 1) / H_TT;
-    const int tile0 = blockIdx.y * tiles_per_split;
+    const int tile0 = wg.split * tiles_per_split;
     const __amdgpu_buffer_rsrc_t t_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint4*>(Th), 0, ntiles * (H_TT * R::ROW16 * 16), 0x00020000);
     if (DMA) {
@@ -631,7 +652,7 @@ __global__ __launch_bounds__(H_QB / (32 * NQB) * 64 * GR, (NQB == 2 ? 2 : 4)) vo
 #pragma unroll
             for (int i = 0; i < 4; ++i) R::put(cl[qb], o[i]);
             const int q = qbase + 32 * qb + r;
-            if (q < nq && h == 0) cand_val[(static_cast<size_t>(q) * slots + blockIdx.y * KNN_C) / KNN_C] = cl[qb];
+            if (q < nq && h == 0) cand_val[(static_cast<size_t>(q) * slots + wg.split * KNN_C) / KNN_C] = cl[qb];
         }
         return;
     }
@@ -640,9 +661,9 @@ __global__ __launch_bounds__(H_QB / (32 * NQB) * 64 * GR, (NQB == 2 ? 2 : 4)) vo
         const int q = qbase + 32 * qb + r;
         R::merge(cl[qb], h);
         if (R::MERGE) {
-            if (q < nq && h == 0) cand_val[(static_cast<size_t>(q) * slots + blockIdx.y * KNN_C) / KNN_C] = cl[qb];
+            if (q < nq && h == 0) cand_val[(static_cast<size_t>(q) * slots + wg.split * KNN_C) / KNN_C] = cl[qb];
         } else {
-            if (q < nq) cand_val[(static_cast<size_t>(q) * slots + (blockIdx.y * 2 + h) * KNN_C) / KNN_C] = cl[qb];
+            if (q < nq) cand_val[(static_cast<size_t>(q) * slots + (wg.split * 2 + h) * KNN_C) / KNN_C] = cl[qb];
         }
     }
 }
@@ -662,9 +683,11 @@ int launch_mfma(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt, i
         attr_done = true;
     }
     dim3 grid((nq + QB - 1) / QB, splits);
+    // a grid that is resident at once takes the XCD-tiled workgroup order (see wg_tile)
+    const int mode = (only_if_ineligible ? 1 : 0) | (static_cast<long long>(grid.x) * grid.y <= 2LL * ctx->n_cu ? 2 : 0);
     pm::ScopedKernelTime t(ctx, "knn_l2_mfma");
     hipLaunchKernelGGL((knn_l2_mfma<NCH, FULL, TT, ABL>), grid, dim3(256), lds, ctx->stream, dq, dt, tnorm, nq, nt, dim,
-                       tiles_per_split, keep_mask, cval, slots, stats, epoch, only_if_ineligible);
+                       tiles_per_split, keep_mask, cval, slots, stats, epoch, mode);
     PM_HIP_CHECK(hipGetLastError());
     return PM_OK;
 }
@@ -718,6 +741,7 @@ int launch_rows288(pm_ctx* ctx, const char* name, const void* Qh, const void* Th
 #define PM_GO(NQB_, DMA_, GR_, THREADS_)                                                                           \
     hipLaunchKernelGGL((knn_mfma_rows288<R, NQB_, DMA_, GR_, ABL>), dim3(nq_pad / H_QB, splits), dim3(THREADS_), lds,  \
                        ctx->stream, q4, t4, nq, nt, tiles_per_split, par, out, slots, stats, epoch, mode)
+    mode = (mode ? 1 : 0) | (static_cast<long long>(nq_pad / H_QB) * splits <= 2LL * ctx->n_cu ? 2 : 0);   // see wg_tile
     bool grouped = false;
     if constexpr (R::MERGE) {
         if (nqb == 3) {

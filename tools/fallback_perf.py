@@ -15,7 +15,10 @@ import points_matching_amd as pm  # noqa: E402
 from points_matching_amd import synth  # noqa: E402
 
 dev = torch.device("cuda", 0)
+stream = torch.cuda.Stream(device=dev)
+torch.cuda.set_stream(stream)              # the events below must sit on the stream the library launches on
 ctx = pm.Context(0)
+ctx.set_stream(stream.cuda_stream)
 out = {"knn_l2": [], "lmeds": []}
 
 
@@ -27,10 +30,10 @@ def time_knn(nq, nt, dim, k, flags, reps=5):
         ctx.bf_knn_l2_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, k, d_o.data_ptr(), flags)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    e0.record(stream)
     for _ in range(reps):
         ctx.bf_knn_l2_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, k, d_o.data_ptr(), flags)
-    e1.record()
+    e1.record(stream)
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     return {"nq": nq, "nt": nt, "dim": dim, "k": k, "flags": flags, "ms": round(ms, 4),
