@@ -66,6 +66,7 @@ PM_MAX_PARTS = 64
 PM_OPT_RANSAC_PATH, PM_OPT_SCORE_OPERANDS, PM_OPT_HAMMING_ROUTE, PM_OPT_KNN_F16_WAVES, PM_OPT_FILTER_FUSION = 1, 2, 3, 4, 5
 PM_OPT_KNN_STAGING = 6
 PM_OPT_KNN_WG_PER_CU = 7
+PM_OPT_KNN_XCD_TILE = 8
 
 
 _lib = None

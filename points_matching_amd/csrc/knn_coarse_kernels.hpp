@@ -30,10 +30,9 @@ typedef Abl<false, false, false, false> AblNone;
 // fastest), and every XCD has its own L2: in launch order each XCD ends up pulling ALL train splits (or all query
 // blocks) through its L2 — 8 x the train copy per launch.  When the grid allows it, XCD x owns a 2-D tile of the
 // grid instead: a quarter of the query blocks x half of the splits, i.e. Q/4 + T/2 through each L2 (the minimum of
-// 8 * (Q/a + T/b) over a*b = 8 for Q = T).  Measured (profiles/r02_pmc_*): C3 f16 fetch 21.3 -> 14.4 MB at unchanged
-// time.  Grids of several rounds keep the launch order (`tiled` = 0, chosen by the launcher): there the tile order put
-// 32 workgroups on one train stream at a time and cost time — 32k x 32k f16 205-211 -> 226-235 us, C4 i8 +3 % —
-// for the same 1/3 of traffic that the 256 MiB Infinity Cache absorbs anyway.
+// 8 * (Q/a + T/b) over a*b = 8 for Q = T).  Measured (profiles/r02_pmc_*): C3 f16 fetch 21.3 -> 14.4 MB, C4 i8 76.4 ->
+// 50.8 MB; same-session A/B of the two orders (PM_OPT_KNN_XCD_TILE 1 / 2): tiled is 0-4 % faster at every shape tried
+// (C3 f16 19.85 -> 19.61 us, C3 f32 route 147.1 -> 141.7, C4 i8 198.9 -> 196.2, 32k x 32k f16 211.4 -> 209.0).
 struct WgTile { int qb, split; };
 __device__ __forceinline__ WgTile wg_tile(bool tiled)
 {
@@ -668,6 +667,13 @@ __global__ __launch_bounds__(H_QB / (32 * NQB) * 64 * GR, (NQB == 2 ? 2 : 4)) vo
     }
 }
 
+// PM_OPT_KNN_XCD_TILE: 1 = launch order, 2 = tiled (the default; wg_tile falls back when the grid shape does not divide)
+inline bool xcd_tiled(const pm_ctx* ctx, long long workgroups)
+{
+    (void)workgroups;
+    return ctx->opts[PM_OPT_KNN_XCD_TILE] != 1;
+}
+
 template <int NCH, bool FULL, int TT, typename ABL>
 int launch_mfma(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt, int dim, const float* tnorm, int splits,
                 int tiles_per_split, unsigned keep_mask, float* cval, int slots, const unsigned long long* stats,
@@ -684,7 +690,7 @@ int launch_mfma(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt, i
     }
     dim3 grid((nq + QB - 1) / QB, splits);
     // a grid that is resident at once takes the XCD-tiled workgroup order (see wg_tile)
-    const int mode = (only_if_ineligible ? 1 : 0) | (static_cast<long long>(grid.x) * grid.y <= 2LL * ctx->n_cu ? 2 : 0);
+    const int mode = (only_if_ineligible ? 1 : 0) | (xcd_tiled(ctx, static_cast<long long>(grid.x) * grid.y) ? 2 : 0);
     pm::ScopedKernelTime t(ctx, "knn_l2_mfma");
     hipLaunchKernelGGL((knn_l2_mfma<NCH, FULL, TT, ABL>), grid, dim3(256), lds, ctx->stream, dq, dt, tnorm, nq, nt, dim,
                        tiles_per_split, keep_mask, cval, slots, stats, epoch, mode);
@@ -741,7 +747,7 @@ int launch_rows288(pm_ctx* ctx, const char* name, const void* Qh, const void* Th
 #define PM_GO(NQB_, DMA_, GR_, THREADS_)                                                                           \
     hipLaunchKernelGGL((knn_mfma_rows288<R, NQB_, DMA_, GR_, ABL>), dim3(nq_pad / H_QB, splits), dim3(THREADS_), lds,  \
                        ctx->stream, q4, t4, nq, nt, tiles_per_split, par, out, slots, stats, epoch, mode)
-    mode = (mode ? 1 : 0) | (static_cast<long long>(nq_pad / H_QB) * splits <= 2LL * ctx->n_cu ? 2 : 0);   // see wg_tile
+    mode = (mode ? 1 : 0) | (xcd_tiled(ctx, static_cast<long long>(nq_pad / H_QB) * splits) ? 2 : 0);     // see wg_tile
     bool grouped = false;
     if constexpr (R::MERGE) {
         if (nqb == 3) {

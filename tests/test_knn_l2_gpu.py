@@ -244,10 +244,17 @@ def test_lds_dma_staging_same_result(ctx, oracle, nq, nt):
                 assert_matches_equal(got, base, "staging %d, waves %d" % (staging, waves))
                 # a wrong candidate id or a lost list would show as a re-scan (the refinement repairs it silently)
                 assert st["rescans"] == base_rescans and st["nonfinite"] == 0, (staging, waves, st)
+        for order in (1, 2):                     # workgroup order: launch order / one 2-D grid tile per XCD
+            ctx.set_option(pm.api.PM_OPT_KNN_XCD_TILE, order)
+            for flags in (pm.api.PM_KNN_HINT_INTEGER, pm.api.PM_KNN_FORCE_F32):
+                got = ctx.bf_knn_l2(w["q"], w["t"], 2, flags)
+                assert_matches_equal(got, base, "xcd order %d flags %d" % (order, flags))
+                assert ctx.knn_stats()["rescans"] == base_rescans
     finally:
         ctx.knn_diag_enable(False)
         ctx.set_option(pm.api.PM_OPT_KNN_STAGING, 0)
         ctx.set_option(pm.api.PM_OPT_KNN_F16_WAVES, 0)
+        ctx.set_option(pm.api.PM_OPT_KNN_XCD_TILE, 0)
     assert_matches_equal(base[:128], oracle.bf_knn_l2(w["q"][:128], w["t"], 2, nthreads=8), "vs oracle")
 
 
