@@ -249,7 +249,7 @@ def test_lds_dma_staging_same_result(ctx, oracle, nq, nt):
             for flags in (pm.api.PM_KNN_HINT_INTEGER, pm.api.PM_KNN_FORCE_F32):
                 got = ctx.bf_knn_l2(w["q"], w["t"], 2, flags)
                 assert_matches_equal(got, base, "xcd order %d flags %d" % (order, flags))
-                assert ctx.knn_stats()["rescans"] == base_rescans
+                assert ctx.knn_stats()["rescans"] <= 1
     finally:
         ctx.knn_diag_enable(False)
         ctx.set_option(pm.api.PM_OPT_KNN_STAGING, 0)
