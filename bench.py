@@ -421,7 +421,8 @@ def main():
         fence()
 
     # ---- the same matcher stage on GENERAL floats (SURF-like unit-norm descriptors, what main.cpp:37-40 produces):
-    # automatic route -> f32-input MFMA coarse pass.  Reported next to `value` (which is the u8-valued SIFT case).
+    # automatic route -> the f16 matrix pass on f16-ROUNDED scaled copies, refinement window widened by the rounding
+    # bound (docs/SPEC.md S1c; results canonical).  Reported next to `value` (which is the u8-valued SIFT case).
     general = None
     if not hamming and args.kind == "sift" and args.workload in ("c2", "c3"):
         wg = synth.pair_workload(nq, nt, dim, seed=wseed, rank=rank, kind="surf")
@@ -446,8 +447,15 @@ def main():
             tt = torch.tensor([g_ms], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             g_ms = float(tt.item())
+        ctx.knn_diag_enable(True)
+        gstep()
+        g_st = ctx.knn_stats()
+        ctx.knn_diag_enable(False)
         general = {"value": float(nq_total) * nt / (g_ms * 1e-3), "match_ms": g_ms, "matches": int(g_n.item()),
-                   "descriptors": "surf (unit-norm general floats), automatic route (f32-input MFMA coarse pass)"}
+                   "descriptors": "surf (unit-norm general floats), automatic route",
+                   "coarse_pass": {0: "f16 MFMA, exact integer copies", 1: "f16 MFMA on f16-rounded scaled copies (SPEC S1c)",
+                                   2: "f32-input MFMA"}.get(g_st["route"], "?"),
+                   "refine": {"rescans": g_st["rescans"], "nonfinite": g_st["nonfinite"]}}
         # leave the arena and the survivor block in the state of the headline workload
         step()
         fence()
@@ -562,7 +570,8 @@ def main():
                                      "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
                                      "kernel_us": round(f32_route_us, 2),
                                      "traffic": pmc_traffic("c3_f32:knn_l2_mfma", nq, nt),
-                                     "dtype": "f32-input MFMA (v_mfma_f32_32x32x2_f32): coarse route for general floats"}
+                                     "dtype": "f32-input MFMA (v_mfma_f32_32x32x2_f32): PM_KNN_FORCE_F32, and the fallback of the "
+                                              "automatic route when the rounded-copy pass withdraws"}
     rk = "ransac_fused" if "ransac_fused" in kern else "ransac_score"
     if rk in kern and n_m:
         flops = 34.0 * n_m * (he - hb)

@@ -78,6 +78,9 @@ int  pm_ctx_timing_get(pm_ctx* ctx, const char* kernel, double* mean_ms, int* la
  * was seen; pm_ctx_knn_stats returns the values of the last such call (synchronises). */
 int  pm_ctx_knn_diag_enable(pm_ctx* ctx, int enable);
 int  pm_ctx_knn_stats(pm_ctx* ctx, int* rescans, int* nonfinite);
+/* ... and which coarse pass the refinement of the last such call read: 0 = f16 matrix pass on exact integer copies,
+ * 1 = f16 matrix pass on rounded copies of general floats, 2 = f32-input matrix pass (synchronises). */
+int  pm_ctx_knn_route(pm_ctx* ctx, int* route);
 /* Explicit per-context switches for tests and A/B timing (the library reads no environment variables).
  * Every option defaults to 0 = automatic; a value outside an option's range is PM_E_INVALID. */
 enum {
@@ -90,7 +93,9 @@ enum {
     PM_OPT_KNN_WG_PER_CU  = 7,  /* f16 coarse kernel: train splits sized for 1 (default) or 2 workgroups per CU     */
     PM_OPT_FILTER_FUSION  = 5,  /* pm_bf_knn_l2_ratio_dev: 1 = filter as its own launch, 2 = inside the refinement  */
     PM_OPT_KNN_XCD_TILE   = 8,  /* coarse kernels, workgroup order: 1 = launch order, 2 = one 2-D grid tile per XCD     */
-    PM_OPT_COUNT_         = 9
+    PM_OPT_KNN_GENERAL_F16 = 9, /* automatic L2 route on general floats: 1 = f32-input matrix pass, 2 = f16-rounded copies
+                                   with a wider refinement window (default)                                     */
+    PM_OPT_COUNT_         = 10
 };
 int  pm_ctx_set_option(pm_ctx* ctx, int option, int value);
 int  pm_ctx_get_option(pm_ctx* ctx, int option, int* value);

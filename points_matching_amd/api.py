@@ -26,7 +26,7 @@ PM_OK, PM_E_INVALID, PM_E_TOO_FEW, PM_E_NO_MODEL, PM_E_HIP, PM_E_NOMEM, PM_E_UNS
 # every extern "C" symbol include/pm.h declares (tests check the library exports all of them)
 EXPORTS = [
     "pm_ctx_create", "pm_ctx_destroy", "pm_ctx_set_stream", "pm_ctx_synchronize",
-    "pm_ctx_timing_enable", "pm_ctx_timing_reset", "pm_ctx_timing_get", "pm_ctx_knn_diag_enable", "pm_ctx_knn_stats",
+    "pm_ctx_timing_enable", "pm_ctx_timing_reset", "pm_ctx_timing_get", "pm_ctx_knn_diag_enable", "pm_ctx_knn_stats", "pm_ctx_knn_route",
     "pm_last_error",
     "pm_status_string", "pm_version",
     "pm_bf_knn_l2_f32", "pm_bf_knn_l2_f32_dev", "pm_bf_knn_hamming_u8", "pm_bf_knn_hamming_u8_dev",
@@ -67,6 +67,7 @@ PM_OPT_RANSAC_PATH, PM_OPT_SCORE_OPERANDS, PM_OPT_HAMMING_ROUTE, PM_OPT_KNN_F16_
 PM_OPT_KNN_STAGING = 6
 PM_OPT_KNN_WG_PER_CU = 7
 PM_OPT_KNN_XCD_TILE = 8
+PM_OPT_KNN_GENERAL_F16 = 9
 
 
 _lib = None
@@ -260,7 +261,9 @@ class Context:
     def knn_stats(self):
         r, nf = C.c_int(), C.c_int()
         _check(lib().pm_ctx_knn_stats(self._h, C.byref(r), C.byref(nf)))
-        return {"rescans": r.value, "nonfinite": nf.value}
+        rt = C.c_int()
+        _check(lib().pm_ctx_knn_route(self._h, C.byref(rt)))
+        return {"rescans": r.value, "nonfinite": nf.value, "route": rt.value}
 
     def filter_ratio_gather_dev(self, dknn_ptr, nq, k, ratio, dkp1_ptr, dkp2_ptr, dgood_ptr, dxy1_ptr,
                                 dxy2_ptr, dn_ptr):

@@ -249,9 +249,9 @@ __global__ __launch_bounds__(256, (TT == 64 ? 2 : 1)) void knn_l2_mfma(
     int nt, int dim, int tiles_per_split, unsigned keep_mask, float* __restrict__ cand_val, int slots,
     const unsigned long long* __restrict__ stats, unsigned epoch, int only_if_ineligible)
 {
-    if (only_if_ineligible & 1) {              // auto mode: the f16 route handles eligible data (bit 1: XCD-tiled grid)
-        const unsigned long long s1 = stats[1];
-        if (!(static_cast<unsigned>(s1 >> 32) == epoch && (s1 & 2ull))) return;
+    if (only_if_ineligible & 1) {              // auto mode (bit 1: XCD-tiled grid): the f16 kernel handles integer data and,
+        const unsigned long long s1 = stats[1], s3 = stats[3];       // on rounded copies, general floats — unless that route withdrew
+        if (!(static_cast<unsigned>(s1 >> 32) == epoch && (s1 & 2ull) && static_cast<unsigned>(s3 >> 32) == epoch)) return;
     }
     using Tile = KnnTile<NCH, FULL, TT>;
     constexpr int LDT = Tile::LDT;
@@ -543,8 +543,9 @@ __global__ __launch_bounds__(H_QB / (32 * NQB) * 64 * GR, (NQB == 2 ? 2 : 4)) vo
     constexpr int THREADS = WPG * 64 * GR;
     static_assert(GR == 1 || (GR == 2 && NQB == 2 && R::MERGE), "row groups: the 64-query form of a merged-list route");
     if (mode & 1) {
-        const unsigned long long s1 = stats[1];
-        if (static_cast<unsigned>(s1 >> 32) == epoch && (s1 & 2ull)) return;      // f32 route takes over
+        const unsigned long long s1 = stats[1], s3 = stats[3];
+        if (static_cast<unsigned>(s1 >> 32) == epoch && (s1 & 2ull) && static_cast<unsigned>(s3 >> 32) == epoch)
+            return;                    // not integer-valued AND the rounded-copy route withdrew: the f32 kernel takes over
     }
     extern __shared__ __attribute__((aligned(16))) uint4 hsm[];                   // [2][H_TT][R::LDS_ROW16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

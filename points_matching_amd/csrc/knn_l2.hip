@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void knn_l2_prep16(const float* __restrict__ Q
             if (live) {
                 norm[row] = s;
                 if (!(s < KNN_INF)) bad |= 3u;
-                else if (is_t) mx = max(mx, f32_bits(s));
+                else mx = max(mx, f32_bits(s));
             }
             f16x8 e0 = {0, 0, 0, 0, 0, 0, 0, 0};
             const f16x8 e1 = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -257,11 +257,133 @@ __global__ __launch_bounds__(256) void knn_l2_prep16(const float* __restrict__ Q
         mx = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
         bad = wbad[0] | wbad[1] | wbad[2] | wbad[3];
         const unsigned long long tag = static_cast<unsigned long long>(epoch) << 32;
-        if (is_t) atomicMax(&stats[0], tag | mx);
+        atomicMax(&stats[is_t ? 0 : 2], tag | mx);           // stats[2]: largest query norm (general-float f16 route)
         // stats[1] is a max, so the flags are published as the values 1 (non-finite), 2 (not
         // f16-eligible) or 3 (both): 3 >= 2 >= 1 keeps "not eligible" visible once any block saw it,
         // and a non-finite input is never eligible.
         if (bad) atomicMax(&stats[1], tag | static_cast<unsigned long long>(bad == 1u ? 3u : bad));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// f16 route for GENERAL floats (automatic mode, data that failed the integer premise — e.g. SURF's unit-norm
+// descriptors, main.cpp:37-40): the same f16 coarse kernel on f16-ROUNDED copies, 16x the f32 matrix rate, with the
+// rounding paid for by a wider refinement window (docs/SPEC.md S1c):
+//     |fl16(q).fl16(t) - q.t| <= (2^-10 + 2^-22) ||q|| ||t||  <=  2^-11 (1 + 2^-12) (||q||^2 + ||t||^2)
+// (every product of two f16 values is exact in the f32 accumulator).  The copies are scaled by powers of two —
+// S_q, S_t with max ||S x|| <= 2^10, from the norm maxima prep16 published — so nothing overflows f16 and elements
+// down to 2^-24 of the largest row keep their 11 bits; the seed chunk carries ||S_t t||^2 rounded to 1/16 (an integer
+// below 2^24 in three exact f16 digits, as on the integer route) against query constants scaled by r = S_q / S_t, so
+// the accumulator ends as S_q S_t (q.t - ||t||^2 / 2) + O(1/32).  The refinement multiplies by 1 / (S_q S_t).
+// The route withdraws (stats[3], the f32 kernel runs instead) when a norm is not finite or r leaves [2^-3, 2^7]
+// (within it every query constant is an exact f16 and the rows padding the last tile stay below every real row).
+// ---------------------------------------------------------------------------------------------
+struct GenScales {
+    float sq, st;        // powers of two
+    float unscale;       // 1 / (sq * st)
+    float qc[3];         // query-row seed constants: -256 r, -2 r, -r / 32
+    bool ok;
+};
+
+__device__ __forceinline__ int half_exp_ceil(float norm2)          // h with sqrt(norm2) < 2^h
+{
+    int e;
+    (void)__builtin_frexpf(norm2, &e);          // norm2 = m * 2^e, 0.5 <= m < 1
+    return (e + 1) >> 1;
+}
+
+__device__ __forceinline__ GenScales gen_scales(unsigned long long s0, unsigned long long s2, unsigned epoch)
+{
+    GenScales g;
+    const float tmax = static_cast<unsigned>(s0 >> 32) == epoch ? __uint_as_float(static_cast<unsigned>(s0)) : 0.f;
+    const float qmax = static_cast<unsigned>(s2 >> 32) == epoch ? __uint_as_float(static_cast<unsigned>(s2)) : 0.f;
+    const int ht = tmax > 0.f ? half_exp_ceil(tmax) : 10, hq = qmax > 0.f ? half_exp_ceil(qmax) : 10;
+    const int j = ht - hq;                       // r = S_q / S_t = 2^j
+    g.ok = ht > -90 && ht < 90 && hq > -90 && hq < 90 && j >= -3 && j <= 7;
+    const int jj = g.ok ? j : 0;
+    g.st = __builtin_ldexpf(1.f, g.ok ? 10 - ht : 0);
+    g.sq = __builtin_ldexpf(1.f, g.ok ? 10 - hq : 0);
+    g.unscale = __builtin_ldexpf(1.f, g.ok ? ht + hq - 20 : 0);
+    g.qc[0] = -__builtin_ldexpf(1.f, 8 + jj);
+    g.qc[1] = -__builtin_ldexpf(1.f, 1 + jj);
+    g.qc[2] = -__builtin_ldexpf(1.f, jj - 5);
+    return g;
+}
+
+__global__ void knn_gen_off(unsigned long long* __restrict__ stats, unsigned epoch)
+{
+    if (threadIdx.x == 0) atomicMax(&stats[3], (static_cast<unsigned long long>(epoch) << 32) | 1ull);
+}
+
+__global__ __launch_bounds__(256) void knn_l2_prep16g(const float* __restrict__ Q, int nq, int nq_pad,
+                                                      const float* __restrict__ T, int nt, int nt_pad, int dim,
+                                                      const float* __restrict__ tnorm, _Float16* __restrict__ Qh,
+                                                      _Float16* __restrict__ Th, unsigned long long* __restrict__ stats,
+                                                      unsigned epoch)
+{
+    const unsigned long long s1 = stats[1];
+    const bool flagged = static_cast<unsigned>(s1 >> 32) == epoch;
+    if (!(flagged && (s1 & 2ull))) return;                  // integer-valued data: prep16's copies stand
+    const GenScales gs = gen_scales(stats[0], stats[2], epoch);
+    if ((s1 & 1ull) || !gs.ok) {                            // non-finite input, or scales too far apart: f32 route
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(&stats[3], (static_cast<unsigned long long>(epoch) << 32) | 1ull);
+        return;
+    }
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int qblocks = nq_pad / 64;
+    const bool is_t = static_cast<int>(blockIdx.x) >= qblocks;
+    const float* x = is_t ? T : Q;
+    const int n = is_t ? nt : nq;
+    _Float16* xh = is_t ? Th : Qh;
+    const float sc = is_t ? gs.st : gs.sq;
+    const int row0 = (is_t ? blockIdx.x - qblocks : blockIdx.x) * 64;
+    const int c0 = 8 * sub;
+    f32x4 ld[4][2];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = row0 + it * 16 + grp;
+        const float* p = x + static_cast<size_t>(row < n ? row : n - 1) * dim;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int c = c0 + 4 * e < dim ? c0 + 4 * e : dim - 4;
+            ld[it][e] = *reinterpret_cast<const f32x4*>(p + c);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = row0 + it * 16 + grp;
+        const bool live = row < n;
+        f16x8 hv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = ld[it][e >> 2][e & 3];
+            if (!(live && c0 + (e & ~3) < dim)) v = 0.f;
+            hv[e] = static_cast<_Float16>(v * sc);          // |v * sc| <= 2^10: in range; round to nearest even
+        }
+        *reinterpret_cast<f16x8*>(xh + static_cast<size_t>(row) * H_ROW + c0) = hv;
+        if (sub == 0) {
+            f16x8 e0 = {0, 0, 0, 0, 0, 0, 0, 0};
+            const f16x8 e1 = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (is_t) {
+                if (live) {
+                    // ||S_t t||^2 <= 2^20, kept to 1/16: an integer below 2^24 + 1
+                    const float z = __builtin_rintf(tnorm[row] * gs.st * gs.st * 16.f);
+                    const unsigned tn = z < 16777216.f ? static_cast<unsigned>(z) : 16777215u;
+                    e0[0] = static_cast<_Float16>(static_cast<float>(tn >> 13));
+                    e0[1] = static_cast<_Float16>(static_cast<float>((tn >> 6) & 127u));
+                    e0[2] = static_cast<_Float16>(static_cast<float>(tn & 63u));
+                } else {
+                    e0[0] = static_cast<_Float16>(60000.f);  // pad row: w = -1.55e7 r, below every real row (>= -2^20 - 2^19 r)
+                    e0[1] = static_cast<_Float16>(60000.f);
+                }
+            } else {
+                e0[0] = static_cast<_Float16>(gs.qc[0]);
+                e0[1] = static_cast<_Float16>(gs.qc[1]);
+                e0[2] = static_cast<_Float16>(gs.qc[2]);
+            }
+            *reinterpret_cast<f16x8*>(xh + static_cast<size_t>(row) * H_ROW + H_DP) = e0;
+            *reinterpret_cast<f16x8*>(xh + static_cast<size_t>(row) * H_ROW + H_DP + 8) = e1;
+        }
     }
 }
 
@@ -291,6 +413,8 @@ struct KnnGeom {
     unsigned lid_mask;
     float eps_coef;           // fp error of the coarse value, times (||q||^2 + max||t||^2)
     float embed_coef;         // truncation by the embedded id, times (||q||^2 + 2 max||t||^2)
+    float eps_coef_gen;       // f16 route on general floats: rounding of the copies, same factor (SPEC S1c)
+    float abs_gen;            // ... plus this many units of the SCALED accumulator (flushed subnormals, seed rounding)
 };
 enum { ROUTE_F32 = 0, ROUTE_F16_HINT = 1, ROUTE_AUTO = 2 };
 
@@ -401,14 +525,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void knn_
     const float tmax = static_cast<unsigned>(s0 >> 32) == epoch ? __uint_as_float(static_cast<unsigned>(s0)) : 0.f;
     const bool flagged = static_cast<unsigned>(s1 >> 32) == epoch;
     const bool ineligible = flagged && (s1 & 2ull);          // data not integer-valued / too large for f16
+    const unsigned long long s3 = stats[3];
+    const bool gen_off = static_cast<unsigned>(s3 >> 32) == epoch;              // the general-float f16 route withdrew
     // which coarse route produced the lists; a wrong integer hint voids them (exact re-scan)
-    const bool use16 = route == ROUTE_F16_HINT || (route == ROUTE_AUTO && !ineligible);
+    const bool general = route == ROUTE_AUTO && ineligible && !gen_off;          // f16-rounded scaled copies
+    const bool use16 = route == ROUTE_F16_HINT || (route == ROUTE_AUTO && (!ineligible || general));
     const bool nonfinite = (flagged && (s1 & 1ull)) || (route == ROUTE_F16_HINT && ineligible);
     const KnnGeom g = use16 ? g16 : g32;
+    float unscale = 1.f, eps_c = g.eps_coef, eps_abs = 0.f;
+    if (general) {
+        const GenScales gs = gen_scales(s0, stats[2], epoch);
+        unscale = gs.unscale;
+        eps_c = g.eps_coef_gen;
+        eps_abs = g.abs_gen * gs.unscale;
+    }
+    if (diag && lane == 0 && !ghost && q == 0) diag[2] = general ? 1u : (use16 ? 0u : 2u);
     const int slots = g.slots, tiles_per_split = g.tiles_per_split, rows_per_tile = g.rows_per_tile;
     const unsigned lid_mask = g.lid_mask;
     // window half-width: fp error of the coarse value + truncation by the embedded row id
-    const float eps = g.eps_coef * (na + tmax) + g.embed_coef * (na + 2.f * tmax);
+    const float eps = eps_c * (na + tmax) + g.embed_coef * (na + 2.f * tmax) + eps_abs;
     const float* cv = g.cand + static_cast<size_t>(q) * slots;
     const int gshift = 31 - __clz(rows_per_tile >> 3);       // groups per tile = rows/8 = 2^gshift
 
@@ -421,7 +556,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void knn_
     for (int i = 0; i < NS; ++i) {
         const int s = lane + 64 * i;
         const float w = s < slots ? cv[s] : -KNN_INF;
-        const float v = w > -1.0e38f ? fmaf(-2.f, w, na) : KNN_INF;
+        const float v = w > -1.0e38f ? fmaf(-2.f, w * unscale, na) : KNN_INF;   // (a power of two: the id bits survive)
         const unsigned gid2 = __float_as_uint(w) & lid_mask;   // (group id << 1) | lane half
         const unsigned gid = gid2 >> 1;
         const int split = s >> 2, hh = static_cast<int>(gid2 & 1u);      // s / KNN_C
@@ -898,6 +1033,10 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
         while ((1 << lid_bits16) < g16.tiles_per_split * (H_TT / 8) * 2) ++lid_bits16;
         g16.lid_mask = (1u << lid_bits16) - 1u;
         g16.eps_coef = 0.f;           // integer data: the f16 products and f32 sums are exact
+        // general floats through the same kernel (SPEC S1c): 2^-11 (1 + 2^-12) for the two roundings, the f32
+        // accumulation of 144 terms, and a quarter on top of the analytic bound for the matrix core's internal order
+        g16.eps_coef_gen = static_cast<float>((4.8828125e-4 * 1.25) + (6.0 * dim + 32.0) * 5.9604644775390625e-8);
+        g16.abs_gen = static_cast<float>(dim) / 16.f + 0.125f;    // flushed f16 subnormals (2^-14 * 2^10 per element) + seed
         g16.embed_coef = static_cast<float>(static_cast<double>(1u << lid_bits16) * 1.1920928955078125e-7 * 1.01);
     }
     if ((want32 && lid_bits32 > 16) || (want16 && lid_bits16 > 16)) {    // > 64k rows per lane stream
@@ -939,14 +1078,14 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
 
     unsigned long long* stats = ctx->knn_stats;          // persistent, epoch-tagged: never cleared
     if (++ctx->knn_epoch == 0u) {              // 2^32 calls: restart the epoch tags
-        PM_HIP_CHECK(hipMemsetAsync(stats, 0, 16, ctx->stream));
+        PM_HIP_CHECK(hipMemsetAsync(stats, 0, 32, ctx->stream));
         ctx->knn_epoch = 1u;
     }
     const unsigned epoch = ctx->knn_epoch;
     unsigned* diag = nullptr;
     if (ctx->knn_diag) {
         diag = ctx->knn_diag_words;
-        PM_HIP_CHECK(hipMemsetAsync(diag, 0, 8, ctx->stream));
+        PM_HIP_CHECK(hipMemsetAsync(diag, 0, 12, ctx->stream));
     }
     {
         pm::ScopedKernelTime t(ctx, "knn_l2_prep");
@@ -956,6 +1095,13 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
         else
             hipLaunchKernelGGL(knn_l2_prep, dim3((nq + 63) / 64 + (nt + 63) / 64), dim3(256), 0, ctx->stream, dq, nq, dt,
                                nt, dim, qnorm, tnorm, stats, epoch);
+        // automatic route: data that failed the integer premise get f16-ROUNDED scaled copies instead (the scales need the
+        // norm maxima of the pass above, hence a launch of its own; it returns at once for integer data)
+        if (route == ROUTE_AUTO && ctx->opts[PM_OPT_KNN_GENERAL_F16] != 1)
+            hipLaunchKernelGGL(knn_l2_prep16g, dim3(nq_pad / 64 + nt_pad / 64), dim3(256), 0, ctx->stream, dq, nq, nq_pad, dt,
+                               nt, nt_pad, dim, tnorm, Qh, Th, stats, epoch);
+        else if (route == ROUTE_AUTO)
+            hipLaunchKernelGGL(knn_gen_off, dim3(1), dim3(64), 0, ctx->stream, stats, epoch);
         PM_HIP_CHECK(hipGetLastError());
     }
     if (want16) {

@@ -259,6 +259,16 @@ int pm_ctx_knn_stats(pm_ctx* ctx, int* rescans, int* nonfinite)
     return PM_OK;
 }
 
+int pm_ctx_knn_route(pm_ctx* ctx, int* route)
+{
+    PM_REQUIRE(ctx != nullptr && route != nullptr, PM_E_INVALID, "null argument");
+    unsigned h = 0;
+    PM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    PM_HIP_CHECK(hipMemcpy(&h, ctx->knn_diag_words + 2, sizeof h, hipMemcpyDeviceToHost));
+    *route = static_cast<int>(h);
+    return PM_OK;
+}
+
 // ---- strong-match filters (slot of main.cpp:49-69) -----------------------------------------
 
 int pm_filter_midpoint(const pm_match* m, int n, double* min_out, double* max_out,

@@ -290,3 +290,82 @@ def test_knn_l2_randomised(ctx, oracle):
         for flags in (0, PM_KNN_HINT_INTEGER, PM_KNN_FORCE_F32, PM_KNN_FORCE_EXACT):
             assert_matches_equal(ctx.bf_knn_l2(q, t, k, flags), want,
                                  "case %d: %s %dx%dx%d k=%d twist=%d flags=%d" % (case, kind, nq, nt, dim, k, twist, flags))
+
+
+def _route_of(ctx, q, t, k=2, flags=0):
+    ctx.knn_diag_enable(True)
+    try:
+        got = ctx.bf_knn_l2(q, t, k, flags)
+        st = ctx.knn_stats()
+    finally:
+        ctx.knn_diag_enable(False)
+    return got, st
+
+
+@pytest.mark.parametrize("nq,nt,dim", [(8192, 8192, 128), (1000, 3000, 64), (257, 129, 128), (50, 5000, 32)])
+def test_general_floats_take_the_rounded_f16_pass(ctx, oracle, nq, nt, dim):
+    """Automatic route, SURF-like unit-norm floats (the reference's own descriptors, main.cpp:37-40): the coarse pass
+    runs on f16-rounded scaled copies (route 1) and the refinement's wider window keeps the result canonical; the
+    f32-input pass (PM_OPT_KNN_GENERAL_F16 = 1, route 2) gives the same bits.  Integer data stay on route 0."""
+    q, t, _ = synth.surf_like(nq, nt, dim, seed=nq + nt)
+    want = oracle.bf_knn_l2(q, t, 2, nthreads=8) if nq <= 1000 else None
+    got, st = _route_of(ctx, q, t)
+    assert st["route"] == 1 and st["nonfinite"] == 0 and st["rescans"] <= max(2, nq // 500), st
+    try:
+        ctx.set_option(pm.api.PM_OPT_KNN_GENERAL_F16, 1)
+        got32, st32 = _route_of(ctx, q, t)
+    finally:
+        ctx.set_option(pm.api.PM_OPT_KNN_GENERAL_F16, 0)
+    assert st32["route"] == 2
+    assert_matches_equal(got, got32, "rounded-f16 pass vs f32-input pass")
+    if want is not None:
+        assert_matches_equal(got, want, "vs oracle")
+    else:
+        sl = slice(3000, 3512)
+        w = oracle.bf_knn_l2(q[sl], t, 2, nthreads=8)
+        w["queryIdx"] += 3000
+        assert_matches_equal(got[sl], w, "slice vs oracle")
+    qi, ti, _ = synth.sift_like(min(nq, 512), min(nt, 2048), dim, seed=3)
+    _, sti = _route_of(ctx, qi, ti)
+    assert sti["route"] == 0
+
+
+def test_general_floats_scales_and_withdrawal(ctx, oracle):
+    """The rounded-copy route rescales by powers of two and withdraws to the f32-input pass when the two matrices'
+    scales are too far apart or an input is not finite; whatever it does, the result is the canonical one."""
+    q, t, _ = synth.surf_like(300, 2000, 128, seed=77)
+    cases = [("tiny", q * np.float32(1e-12), t * np.float32(1e-12), 1),
+             ("huge", q * np.float32(3e15), t * np.float32(3e15), 1),
+             ("train x64", q, t * np.float32(64.0), 1),
+             ("query x1000 (ratio out of range)", q * np.float32(1000.0), t, 2),
+             ("train x1e4 (ratio out of range)", q, t * np.float32(1e4), 2)]
+    t_out = t.copy(); t_out[17] *= np.float32(50.0)              # one large row sets the train scale (r = 2^6) ...
+    cases.append(("one large train row", q, t_out, 1))
+    t_out = t.copy(); t_out[17] *= np.float32(5000.0)            # ... a giant one pushes r out of range
+    cases.append(("one giant train row", q, t_out, 2))
+    q_mix = q.copy(); q_mix[::2] *= np.float32(1e-4)
+    cases.append(("queries of mixed scale", q_mix, t, 1))
+    for name, qq, tt, route in cases:
+        got, st = _route_of(ctx, qq, tt)
+        assert st["route"] == route, (name, st)
+        assert_matches_equal(got, oracle.bf_knn_l2(qq, tt, 2, nthreads=8), name)
+    t_nan = t.copy(); t_nan[5, 3] = np.inf
+    got, st = _route_of(ctx, q, t_nan)
+    assert st["nonfinite"] == 1
+    assert_matches_equal(got, oracle.bf_knn_l2(q, t_nan, 2, nthreads=8), "non-finite input")
+
+
+def test_general_floats_near_ties_below_f16_resolution(ctx, oracle):
+    """Train rows that differ by less than an f16 ulp: the rounded copies are IDENTICAL, the window must still deliver
+    every one of them to the refinement (runs longer than a candidate list force the re-scan branch)."""
+    rng = np.random.default_rng(21)
+    q, t, _ = synth.surf_like(128, 4096, 128, seed=31)
+    for i in range(0, 128, 3):
+        base = q[i].copy()
+        n_dup = int(rng.integers(2, 24))
+        rows = rng.choice(4096, size=n_dup, replace=False)
+        for r in rows:
+            t[r] = base * (1.0 + np.float32(rng.uniform(-3e-5, 3e-5, size=128)))
+    got, st = _route_of(ctx, q, t)
+    assert st["route"] == 1
+    assert_matches_equal(got, oracle.bf_knn_l2(q, t, 2, nthreads=8), "near ties")
