@@ -1033,11 +1033,13 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
         while ((1 << lid_bits16) < g16.tiles_per_split * (H_TT / 8) * 2) ++lid_bits16;
         g16.lid_mask = (1u << lid_bits16) - 1u;
         g16.eps_coef = 0.f;           // integer data: the f16 products and f32 sums are exact
-        // general floats through the same kernel (SPEC S1c): 2^-11 (1 + 2^-12) for the two roundings, the f32
-        // accumulation of 144 terms, and a quarter on top of the analytic bound for the matrix core's internal order
-        g16.eps_coef_gen = static_cast<float>((4.8828125e-4 * 1.25) + (6.0 * dim + 32.0) * 5.9604644775390625e-8);
-        g16.abs_gen = static_cast<float>(dim) / 16.f + 0.125f;    // flushed f16 subnormals (2^-14 * 2^10 per element) + seed
-        g16.embed_coef = static_cast<float>(static_cast<double>(1u << lid_bits16) * 1.1920928955078125e-7 * 1.01);
+        // general floats through the same kernel (SPEC S1c).  d2a = ||q||^2 - 2w, so the window pays TWICE the error of
+        // w: 2 (2^-10 + 2^-22) ||q|| ||t|| <= 2^-10 (1 + 2^-12) (||q||^2 + ||t||^2) for the two roundings, an eighth on top
+        // for the matrix core's internal summation order, plus the f32 route's term for the accumulation and the norms
+        g16.eps_coef_gen = static_cast<float>(9.765625e-4 * 1.125 + (6.0 * dim + 32.0) * 5.9604644775390625e-8 * 1.001);
+        // ... and, in units of the SCALED accumulator: f16 subnormals flushed on either operand (2 * 2^-14 * 2^10 per
+        // element) and the seed's 1/16 rounding times r / 2 <= 64, both doubled
+        g16.abs_gen = static_cast<float>(dim) / 4.f + 4.f;
     }
     if ((want32 && lid_bits32 > 16) || (want16 && lid_bits16 > 16)) {    // > 64k rows per lane stream
         const int rx = run_exact(ctx, dq, nq, dt, nt, dim, k, dout);
