@@ -1040,6 +1040,7 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
         // ... and, in units of the SCALED accumulator: f16 subnormals flushed on either operand (2 * 2^-14 * 2^10 per
         // element) and the seed's 1/16 rounding times r / 2 <= 64, both doubled
         g16.abs_gen = static_cast<float>(dim) / 4.f + 4.f;
+        g16.embed_coef = static_cast<float>(static_cast<double>(1u << lid_bits16) * 1.1920928955078125e-7 * 1.01);
     }
     if ((want32 && lid_bits32 > 16) || (want16 && lid_bits16 > 16)) {    // > 64k rows per lane stream
         const int rx = run_exact(ctx, dq, nq, dt, nt, dim, k, dout);
