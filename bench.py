@@ -202,6 +202,8 @@ def main():
                     help="A/B timing: PM_OPT_RANSAC_PATH (0 automatic, 1 solve + score launches, 2 one-launch kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="skip the general-float leg and the forced f32-route leg (clean kernel traces of the headline path)")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` without a launcher: start the N ranks ourselves.  This parent has not
@@ -408,15 +410,16 @@ def main():
         ctx.bf_knn_l2_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, K, d_knn.data_ptr(), knn_flags)
         kstats = ctx.knn_stats()
         ctx.knn_diag_enable(False)
-        # the general-float coarse route (f32-input MFMA) on the same data, for its own roofline line
-        ctx.timing_enable(True)
-        ctx.timing_reset()
-        for _ in range(args.steps):
-            ctx.bf_knn_l2_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, K, d_knn.data_ptr(),
-                              pm.api.PM_KNN_FORCE_F32)
-        fence()
-        f32_route_us = ctx.timing_get("knn_l2_mfma")[0] * 1e3
-        ctx.timing_enable(False)
+        # the f32-input coarse pass (PM_KNN_FORCE_F32) on the same data, for its own roofline line
+        if not args.headline_only:
+            ctx.timing_enable(True)
+            ctx.timing_reset()
+            for _ in range(args.steps):
+                ctx.bf_knn_l2_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, K, d_knn.data_ptr(),
+                                  pm.api.PM_KNN_FORCE_F32)
+            fence()
+            f32_route_us = ctx.timing_get("knn_l2_mfma")[0] * 1e3
+            ctx.timing_enable(False)
         ctx.bf_knn_l2_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, K, d_knn.data_ptr(), knn_flags)
         fence()
 
@@ -424,7 +427,7 @@ def main():
     # automatic route -> the f16 matrix pass on f16-ROUNDED scaled copies, refinement window widened by the rounding
     # bound (docs/SPEC.md S1c; results canonical).  Reported next to `value` (which is the u8-valued SIFT case).
     general = None
-    if not hamming and args.kind == "sift" and args.workload in ("c2", "c3"):
+    if not hamming and args.kind == "sift" and args.workload in ("c2", "c3") and not args.headline_only:
         wg = synth.pair_workload(nq, nt, dim, seed=wseed, rank=rank, kind="surf")
         g_q = torch.from_numpy(np.ascontiguousarray(wg["q"])).to(dev)
         g_t = torch.from_numpy(np.ascontiguousarray(wg["t"])).to(dev)

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void knn_l2_prep16(const float* __restrict__ Q
                                                      const float* __restrict__ T, int nt, int nt_pad, int dim,
                                                      float* __restrict__ qnorm, float* __restrict__ tnorm,
                                                      _Float16* __restrict__ Qh, _Float16* __restrict__ Th,
-                                                     unsigned long long* __restrict__ stats, unsigned epoch)
+                                                     unsigned long long* __restrict__ stats, unsigned epoch, int want_qmax)
 {
     __shared__ unsigned wmax[4];
     __shared__ unsigned wbad[4];
@@ -257,7 +257,11 @@ __global__ __launch_bounds__(256) void knn_l2_prep16(const float* __restrict__ Q
         mx = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
         bad = wbad[0] | wbad[1] | wbad[2] | wbad[3];
         const unsigned long long tag = static_cast<unsigned long long>(epoch) << 32;
-        atomicMax(&stats[is_t ? 0 : 2], tag | mx);           // stats[2]: largest query norm (general-float f16 route)
+        // stats[2]: largest query norm, for the general-float f16 route only (256 atomics on one line instead of 128
+        // cost the launch 1.6 us at C3: the automatic route asks for it, the others do not)
+        // (testing the word before the atomic was measured slower: the dependent load costs more than the atomic)
+        if (is_t) atomicMax(&stats[0], tag | mx);
+        else if (want_qmax) atomicMax(&stats[2], tag | mx);
         // stats[1] is a max, so the flags are published as the values 1 (non-finite), 2 (not
         // f16-eligible) or 3 (both): 3 >= 2 >= 1 keeps "not eligible" visible once any block saw it,
         // and a non-finite input is never eligible.
@@ -504,7 +508,9 @@ constexpr unsigned KF_SPIN_LIMIT = 1u << 22;
 // candidates spread over them adds rounds.  (This kernel is VALU-issue bound: one wave per query.)
 // (amdgpu_num_sgpr: the fused tail's pointers pushed the kernel to 95 SGPRs, and above 80 a CU admits 7 instead of 8
 // of these workgroups — 1792 of the 2048 at C3, i.e. a second round: 10 -> 20 us.  Capped, the kernel stays at 8.)
-template <bool VEC4, int NS, bool FUSE>
+// GEN: the automatic route may have ranked general floats on rounded copies (SPEC S1c); the other routes are
+// instantiated without that code (its scalar loads and the rescale cost the headline path 0.6 us at C3).
+template <bool VEC4, int NS, bool FUSE, bool GEN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void knn_l2_refine(
     const float* __restrict__ Q, const float* __restrict__ T, const float* __restrict__ qnorm,
     const unsigned long long* __restrict__ stats, unsigned epoch, unsigned* __restrict__ diag, int nq, int nt,
@@ -525,19 +531,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void knn_
     const float tmax = static_cast<unsigned>(s0 >> 32) == epoch ? __uint_as_float(static_cast<unsigned>(s0)) : 0.f;
     const bool flagged = static_cast<unsigned>(s1 >> 32) == epoch;
     const bool ineligible = flagged && (s1 & 2ull);          // data not integer-valued / too large for f16
-    const unsigned long long s3 = stats[3];
-    const bool gen_off = static_cast<unsigned>(s3 >> 32) == epoch;              // the general-float f16 route withdrew
     // which coarse route produced the lists; a wrong integer hint voids them (exact re-scan)
-    const bool general = route == ROUTE_AUTO && ineligible && !gen_off;          // f16-rounded scaled copies
+    bool general = false;                                                        // f16-rounded scaled copies
+    if constexpr (GEN) {
+        const unsigned long long s3 = stats[3];
+        const bool gen_off = static_cast<unsigned>(s3 >> 32) == epoch;          // the general-float f16 route withdrew
+        general = route == ROUTE_AUTO && ineligible && !gen_off;
+    }
     const bool use16 = route == ROUTE_F16_HINT || (route == ROUTE_AUTO && (!ineligible || general));
     const bool nonfinite = (flagged && (s1 & 1ull)) || (route == ROUTE_F16_HINT && ineligible);
     const KnnGeom g = use16 ? g16 : g32;
     float unscale = 1.f, eps_c = g.eps_coef, eps_abs = 0.f;
-    if (general) {
-        const GenScales gs = gen_scales(s0, stats[2], epoch);
-        unscale = gs.unscale;
-        eps_c = g.eps_coef_gen;
-        eps_abs = g.abs_gen * gs.unscale;
+    if constexpr (GEN) {
+        if (general) {
+            const GenScales gs = gen_scales(s0, stats[2], epoch);
+            unscale = gs.unscale;
+            eps_c = g.eps_coef_gen;
+            eps_abs = g.abs_gen * gs.unscale;
+        }
     }
     if (diag && lane == 0 && !ghost && q == 0) diag[2] = general ? 1u : (use16 ? 0u : 2u);
     const int slots = g.slots, tiles_per_split = g.tiles_per_split, rows_per_tile = g.rows_per_tile;
@@ -556,7 +567,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void knn_
     for (int i = 0; i < NS; ++i) {
         const int s = lane + 64 * i;
         const float w = s < slots ? cv[s] : -KNN_INF;
-        const float v = w > -1.0e38f ? fmaf(-2.f, w * unscale, na) : KNN_INF;   // (a power of two: the id bits survive)
+        const float ws = GEN ? w * unscale : w;                                  // (a power of two: the id bits survive)
+        const float v = w > -1.0e38f ? fmaf(-2.f, ws, na) : KNN_INF;
         const unsigned gid2 = __float_as_uint(w) & lid_mask;   // (group id << 1) | lane half
         const unsigned gid = gid2 >> 1;
         const int split = s >> 2, hh = static_cast<int>(gid2 & 1u);      // s / KNN_C
@@ -1094,7 +1106,7 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
         pm::ScopedKernelTime t(ctx, "knn_l2_prep");
         if (want16)
             hipLaunchKernelGGL(knn_l2_prep16, dim3(nq_pad / 64 + nt_pad / 64), dim3(256), 0, ctx->stream, dq, nq, nq_pad,
-                               dt, nt, nt_pad, dim, qnorm, tnorm, Qh, Th, stats, epoch);
+                               dt, nt, nt_pad, dim, qnorm, tnorm, Qh, Th, stats, epoch, route == ROUTE_AUTO ? 1 : 0);
         else
             hipLaunchKernelGGL(knn_l2_prep, dim3((nq + 63) / 64 + (nt + 63) / 64), dim3(256), 0, ctx->stream, dq, nq, dt,
                                nt, dim, qnorm, tnorm, stats, epoch);
@@ -1120,14 +1132,16 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
     {
         pm::ScopedKernelTime t(ctx, "knn_l2_refine");
         const int max_slots = (want16 ? g16.slots : 0) > (want32 ? g32.slots : 0) ? g16.slots : g32.slots;
-#define PM_REFINE2(NS_, FUSE_)                                                                                     \
-    hipLaunchKernelGGL((knn_l2_refine<true, NS_, FUSE_>), dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, dq, dt, qnorm, \
-                       stats, epoch, diag, nq, nt, dim, k, g16, g32, route, dout, fz)
+#define PM_REFINE3(NS_, FUSE_, GEN_)                                                                                 \
+    hipLaunchKernelGGL((knn_l2_refine<true, NS_, FUSE_, GEN_>), dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, dq, dt,  \
+                       qnorm, stats, epoch, diag, nq, nt, dim, k, g16, g32, route, dout, fz)
+#define PM_REFINE2(NS_, FUSE_) do { if (route == ROUTE_AUTO) PM_REFINE3(NS_, FUSE_, true); else PM_REFINE3(NS_, FUSE_, false); } while (0)
 #define PM_REFINE(NS_) do { if (fuse) PM_REFINE2(NS_, true); else PM_REFINE2(NS_, false); } while (0)
         if (max_slots <= 64) PM_REFINE(1);
         else if (max_slots <= 128) PM_REFINE(2);
         else if (max_slots <= 256) PM_REFINE(4);
         else PM_REFINE(8);
+#undef PM_REFINE3
 #undef PM_REFINE2
 #undef PM_REFINE
         PM_HIP_CHECK(hipGetLastError());

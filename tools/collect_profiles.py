@@ -36,12 +36,12 @@ if os.path.exists(os.path.join(src, "h2d_ceiling.txt")):
         "# tools/h2d_ceiling.py on the GPU box: pinned host -> device copy rate by chunk size and stream count\n" + "".join(txt))
 
 # ---- kernel traces
-for cfg in ("c3", "c4"):
+for cfg in ("c3", "c4", "c3_surf"):
     st = glob.glob(os.path.join(src, "trace_" + cfg, "*", "*kernel_stats.csv"))
     tr = glob.glob(os.path.join(src, "trace_" + cfg, "*", "*kernel_trace.csv"))
     if st:
         shutil.copy(st[0], os.path.join(P, "%s_bench_%s_kernel_stats.csv" % (pre, cfg)))
-    if tr and cfg == "c3":
+    if tr and cfg in ("c3", "c3_surf"):
         per = defaultdict(list)
         for r in csv.DictReader(open(tr[0])):
             per[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
@@ -52,17 +52,16 @@ for cfg in ("c3", "c4"):
                 continue
             short = m.group(0)
             counted = v
-            if "knn_mfma_rows288" in short:                 # automatic-mode launches of the general-float leg exit at once
-                counted = [x for x in v if x > 8.0]
+            if "knn_mfma_rows288" in short or short.startswith("knn_l2_mfma"):   # launches that exit in their first instructions
+                counted = [x for x in v if x > 8.0] or v
             out[short] = {"calls": len(v), "calls_counted": len(counted), "avg_us": round(sum(counted) / max(1, len(counted)), 3),
                           "min_us": round(min(counted), 3) if counted else None, "max_us": round(max(counted), 3) if counted else None}
-        json.dump({"note": "per-kernel durations from the rocprofv3 --kernel-trace of `bench.py --steps 20 --warmup 5 "
-                           "--no-cpu-baseline --no-verify --sustain-seconds 0` (the *_kernel_stats.csv next to this file is "
-                           "rocprofv3's own --stats summary of the same run). bench.py also times the general-float leg, which "
-                           "launches knn_mfma_rows288<RouteF16> in automatic mode where it exits in its first instructions "
-                           "(< 8 us): those launches are excluded from `calls_counted`, and they are what pulls the --stats "
-                           "average of that kernel down.", "kernels": out},
-                  open(os.path.join(P, "%s_bench_c3_kernel_durations.json" % pre), "w"), indent=1)
+        json.dump({"note": "per-kernel durations from the rocprofv3 --kernel-trace of `bench.py%s --steps 20 --warmup 5 "
+                           "--no-cpu-baseline --no-verify --sustain-seconds 0 --headline-only` (the *_kernel_stats.csv next to "
+                           "this file is rocprofv3's own --stats summary of the same run). Launches of a coarse kernel that "
+                           "exit in their first instructions (the automatic route's unused fallback, < 8 us) are excluded from "
+                           "`calls_counted`." % (" --kind surf" if cfg == "c3_surf" else ""), "kernels": out},
+                  open(os.path.join(P, "%s_bench_%s_kernel_durations.json" % (pre, cfg)), "w"), indent=1)
 
 # ---- PMC summaries
 summ = {}

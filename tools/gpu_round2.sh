@@ -28,7 +28,8 @@ step bench_w2s 300 bash -c "python bench.py --gpus 2 --backend gloo --single-dev
 step fallback 300 bash -c "python tools/fallback_perf.py > $O/fallback_perf.json 2> $O/fallback_perf.err"
 step h2d 200 bash -c "python tools/h2d_ceiling.py > $O/h2d_ceiling.txt 2>&1"
 cd /tmp && export TMPDIR=/tmp
-step trace_c3 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c3 -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-verify --sustain-seconds 0 > $O/trace_c3.log 2>&1
+step trace_c3 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c3 -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-verify --sustain-seconds 0 --headline-only > $O/trace_c3.log 2>&1
+step trace_c3_surf 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c3_surf -- python3 $R/bench.py --kind surf --steps 20 --warmup 5 --no-cpu-baseline --no-verify --sustain-seconds 0 --headline-only > $O/trace_c3_surf.log 2>&1
 step trace_c4 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_c4 -- python3 $R/bench.py --workload c4 --steps 10 --warmup 3 --no-cpu-baseline --no-verify --sustain-seconds 0 > $O/trace_c4.log 2>&1
 fi
 pass() {   # pass <dir> <driver + args> -- <counters...>
