@@ -37,8 +37,9 @@ if os.path.exists(os.path.join(src, "h2d_ceiling.txt")):
 
 # ---- kernel traces
 for cfg in ("c3", "c4", "c3_surf"):
-    st = glob.glob(os.path.join(src, "trace_" + cfg, "*", "*kernel_stats.csv"))
-    tr = glob.glob(os.path.join(src, "trace_" + cfg, "*", "*kernel_trace.csv"))
+    # (a re-run leaves the earlier run's files next to the new ones: newest first)
+    st = sorted(glob.glob(os.path.join(src, "trace_" + cfg, "*", "*kernel_stats.csv")), key=os.path.getmtime, reverse=True)
+    tr = sorted(glob.glob(os.path.join(src, "trace_" + cfg, "*", "*kernel_trace.csv")), key=os.path.getmtime, reverse=True)
     if st:
         shutil.copy(st[0], os.path.join(P, "%s_bench_%s_kernel_stats.csv" % (pre, cfg)))
     if tr and cfg in ("c3", "c3_surf"):

@@ -7,6 +7,7 @@ TAG=${1:-r2}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
+rm -rf $O/pmc_* $O/trace_*            # rocprofv3 adds files next to an earlier run's: never mix two builds
 cd $R
 step() {   # step <name> <seconds> <cmd...>
     local name=$1 secs=$2; shift 2
