@@ -93,8 +93,8 @@ enum {
     PM_OPT_KNN_WG_PER_CU  = 7,  /* f16 coarse kernel: train splits sized for 1 (default) or 2 workgroups per CU     */
     PM_OPT_FILTER_FUSION  = 5,  /* pm_bf_knn_l2_ratio_dev: 1 = filter as its own launch, 2 = inside the refinement  */
     PM_OPT_KNN_XCD_TILE   = 8,  /* coarse kernels, workgroup order: 1 = launch order, 2 = one 2-D grid tile per XCD     */
-    PM_OPT_KNN_GENERAL_F16 = 9, /* automatic L2 route on general floats: 1 = f32-input matrix pass, 2 = f16-rounded copies
-                                   with a wider refinement window (default)                                     */
+    PM_OPT_KNN_GENERAL_F16 = 9, /* automatic L2 route on general floats: 1 = f32-input matrix pass (enqueued next to the
+                                   f16 one), 2 = f16-rounded scaled copies, wider refinement window (default)   */
     PM_OPT_COUNT_         = 10
 };
 int  pm_ctx_set_option(pm_ctx* ctx, int option, int value);

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void knn_l2_prep16(const float* __restrict__ Q
                                                      const float* __restrict__ T, int nt, int nt_pad, int dim,
                                                      float* __restrict__ qnorm, float* __restrict__ tnorm,
                                                      _Float16* __restrict__ Qh, _Float16* __restrict__ Th,
-                                                     unsigned long long* __restrict__ stats, unsigned epoch, int want_qmax)
+                                                     unsigned long long* __restrict__ stats, unsigned epoch)
 {
     __shared__ unsigned wmax[4];
     __shared__ unsigned wbad[4];
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void knn_l2_prep16(const float* __restrict__ Q
             if (live) {
                 norm[row] = s;
                 if (!(s < KNN_INF)) bad |= 3u;
-                else mx = max(mx, f32_bits(s));
+                else if (is_t) mx = max(mx, f32_bits(s));
             }
             f16x8 e0 = {0, 0, 0, 0, 0, 0, 0, 0};
             const f16x8 e1 = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -257,11 +257,7 @@ __global__ __launch_bounds__(256) void knn_l2_prep16(const float* __restrict__ Q
         mx = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
         bad = wbad[0] | wbad[1] | wbad[2] | wbad[3];
         const unsigned long long tag = static_cast<unsigned long long>(epoch) << 32;
-        // stats[2]: largest query norm, for the general-float f16 route only (256 atomics on one line instead of 128
-        // cost the launch 1.6 us at C3: the automatic route asks for it, the others do not)
-        // (testing the word before the atomic was measured slower: the dependent load costs more than the atomic)
         if (is_t) atomicMax(&stats[0], tag | mx);
-        else if (want_qmax) atomicMax(&stats[2], tag | mx);
         // stats[1] is a max, so the flags are published as the values 1 (non-finite), 2 (not
         // f16-eligible) or 3 (both): 3 >= 2 >= 1 keeps "not eligible" visible once any block saw it,
         // and a non-finite input is never eligible.
@@ -274,21 +270,18 @@ __global__ __launch_bounds__(256) void knn_l2_prep16(const float* __restrict__ Q
 // descriptors, main.cpp:37-40): the same f16 coarse kernel on f16-ROUNDED copies, 16x the f32 matrix rate, with the
 // rounding paid for by a wider refinement window (docs/SPEC.md S1c):
 //     |fl16(q).fl16(t) - q.t| <= (2^-10 + 2^-22) ||q|| ||t||  <=  2^-11 (1 + 2^-12) (||q||^2 + ||t||^2)
-// (every product of two f16 values is exact in the f32 accumulator).  The copies are scaled by powers of two —
-// S_q, S_t with max ||S x|| <= 2^10, from the norm maxima prep16 published — so nothing overflows f16 and elements
-// down to 2^-24 of the largest row keep their 11 bits; the seed chunk carries ||S_t t||^2 rounded to 1/16 (an integer
-// below 2^24 in three exact f16 digits, as on the integer route) against query constants scaled by r = S_q / S_t, so
-// the accumulator ends as S_q S_t (q.t - ||t||^2 / 2) + O(1/32).  The refinement multiplies by 1 / (S_q S_t).
-// The route withdraws (stats[3], the f32 kernel runs instead) when a norm is not finite or r leaves [2^-3, 2^7]
-// (within it every query constant is an exact f16 and the rows padding the last tile stay below every real row).
+// (every product of two f16 values is exact in the f32 accumulator).  The copies are scaled by powers of two:
+//   train rows by ONE factor S_t = 2^(10 - h_t), h_t = ceil(log2 max ||t||) from the norm maximum prep16 published
+//     (a query ranks train rows against each other: they need a common scale), so ||S_t t|| < 2^10;
+//   query row i by its OWN factor S_i = S_t 2^j, j = clamp(h_t - h_i, -3, 7) (a query's ranking does not depend on
+//     its scale): ||S_i q_i|| < 2^10 whenever its norm is within [2^-7, 2^3] of the train maximum, smaller rows lose
+//     bits (their window is wide in relation to their distances: candidates, at worst re-scans), rows more than
+//     8x larger than every train row are not ranked at all (NaN seed: the refinement scans them exactly).
+// The seed chunk carries ||S_t t||^2 rounded to 1/16 (an integer below 2^24 in three exact f16 digits, as on the
+// integer route) against query constants (-256, -2, -1/32) 2^j, so the accumulator of (i, t) ends as
+// S_i S_t (q_i.t - ||t||^2 / 2) + O(2^j / 64); the refinement multiplies by 1 / (S_i S_t).  Within j in [-3, 7] every
+// query constant is an exact f16 and the rows padding the last tile (A2 = A1 = 60000) stay below every real row.
 // ---------------------------------------------------------------------------------------------
-struct GenScales {
-    float sq, st;        // powers of two
-    float unscale;       // 1 / (sq * st)
-    float qc[3];         // query-row seed constants: -256 r, -2 r, -r / 32
-    bool ok;
-};
-
 __device__ __forceinline__ int half_exp_ceil(float norm2)          // h with sqrt(norm2) < 2^h
 {
     int e;
@@ -296,21 +289,31 @@ __device__ __forceinline__ int half_exp_ceil(float norm2)          // h with sqr
     return (e + 1) >> 1;
 }
 
-__device__ __forceinline__ GenScales gen_scales(unsigned long long s0, unsigned long long s2, unsigned epoch)
+__device__ __forceinline__ int train_half_exp(unsigned long long s0, unsigned epoch)
 {
-    GenScales g;
     const float tmax = static_cast<unsigned>(s0 >> 32) == epoch ? __uint_as_float(static_cast<unsigned>(s0)) : 0.f;
-    const float qmax = static_cast<unsigned>(s2 >> 32) == epoch ? __uint_as_float(static_cast<unsigned>(s2)) : 0.f;
-    const int ht = tmax > 0.f ? half_exp_ceil(tmax) : 10, hq = qmax > 0.f ? half_exp_ceil(qmax) : 10;
-    const int j = ht - hq;                       // r = S_q / S_t = 2^j
-    g.ok = ht > -90 && ht < 90 && hq > -90 && hq < 90 && j >= -3 && j <= 7;
-    const int jj = g.ok ? j : 0;
-    g.st = __builtin_ldexpf(1.f, g.ok ? 10 - ht : 0);
-    g.sq = __builtin_ldexpf(1.f, g.ok ? 10 - hq : 0);
-    g.unscale = __builtin_ldexpf(1.f, g.ok ? ht + hq - 20 : 0);
-    g.qc[0] = -__builtin_ldexpf(1.f, 8 + jj);
-    g.qc[1] = -__builtin_ldexpf(1.f, 1 + jj);
-    g.qc[2] = -__builtin_ldexpf(1.f, jj - 5);
+    return tmax > 0.f ? half_exp_ceil(tmax) : 10;
+}
+
+struct QueryScale {
+    float sq;            // S_i
+    float unscale;       // 1 / (S_i S_t)
+    float qc[3];         // seed constants of the query row
+    bool unranked;       // ||q_i|| > 8 max ||t||: no f16 image
+};
+
+__device__ __forceinline__ QueryScale query_scale(int ht, float qnorm2)     // the SAME function in prep16g and the refinement
+{
+    QueryScale g;
+    const int hq = qnorm2 > 0.f ? half_exp_ceil(qnorm2) : ht;
+    const int j = ht - hq;
+    g.unranked = j < -3;
+    const int jc = j < -3 ? -3 : (j > 7 ? 7 : j);
+    g.sq = __builtin_ldexpf(1.f, 10 - ht + jc);
+    g.unscale = __builtin_ldexpf(1.f, 2 * ht - 20 - jc);
+    g.qc[0] = -__builtin_ldexpf(1.f, 8 + jc);
+    g.qc[1] = -__builtin_ldexpf(1.f, 1 + jc);
+    g.qc[2] = -__builtin_ldexpf(1.f, jc - 5);
     return g;
 }
 
@@ -321,48 +324,51 @@ __global__ void knn_gen_off(unsigned long long* __restrict__ stats, unsigned epo
 
 __global__ __launch_bounds__(256) void knn_l2_prep16g(const float* __restrict__ Q, int nq, int nq_pad,
                                                       const float* __restrict__ T, int nt, int nt_pad, int dim,
-                                                      const float* __restrict__ tnorm, _Float16* __restrict__ Qh,
-                                                      _Float16* __restrict__ Th, unsigned long long* __restrict__ stats,
-                                                      unsigned epoch)
+                                                      const float* __restrict__ qnorm, const float* __restrict__ tnorm,
+                                                      _Float16* __restrict__ Qh, _Float16* __restrict__ Th,
+                                                      const unsigned long long* __restrict__ stats, unsigned epoch)
 {
     const unsigned long long s1 = stats[1];
     const bool flagged = static_cast<unsigned>(s1 >> 32) == epoch;
     if (!(flagged && (s1 & 2ull))) return;                  // integer-valued data: prep16's copies stand
-    const GenScales gs = gen_scales(stats[0], stats[2], epoch);
-    if ((s1 & 1ull) || !gs.ok) {                            // non-finite input, or scales too far apart: f32 route
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(&stats[3], (static_cast<unsigned long long>(epoch) << 32) | 1ull);
-        return;
-    }
+    if (s1 & 1ull) return;                                  // a non-finite input: the refinement scans everything anyway
+    const int ht = train_half_exp(stats[0], epoch);
+    const float st = __builtin_ldexpf(1.f, 10 - ht);
     const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const int qblocks = nq_pad / 64;
     const bool is_t = static_cast<int>(blockIdx.x) >= qblocks;
     const float* x = is_t ? T : Q;
     const int n = is_t ? nt : nq;
     _Float16* xh = is_t ? Th : Qh;
-    const float sc = is_t ? gs.st : gs.sq;
     const int row0 = (is_t ? blockIdx.x - qblocks : blockIdx.x) * 64;
     const int c0 = 8 * sub;
     f32x4 ld[4][2];
+    float nrm[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int row = row0 + it * 16 + grp;
-        const float* p = x + static_cast<size_t>(row < n ? row : n - 1) * dim;
+        const int rr = row < n ? row : n - 1;
+        const float* p = x + static_cast<size_t>(rr) * dim;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int c = c0 + 4 * e < dim ? c0 + 4 * e : dim - 4;
             ld[it][e] = *reinterpret_cast<const f32x4*>(p + c);
         }
+        nrm[it] = (is_t ? tnorm : qnorm)[rr];
     }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int row = row0 + it * 16 + grp;
         const bool live = row < n;
+        QueryScale qs = query_scale(ht, nrm[it]);
+        const float sc = is_t ? st : qs.sq;
+        const bool zero = !live || (!is_t && qs.unranked);
         f16x8 hv;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float v = ld[it][e >> 2][e & 3];
-            if (!(live && c0 + (e & ~3) < dim)) v = 0.f;
-            hv[e] = static_cast<_Float16>(v * sc);          // |v * sc| <= 2^10: in range; round to nearest even
+            if (zero || !(c0 + (e & ~3) < dim)) v = 0.f;
+            hv[e] = static_cast<_Float16>(v * sc);          // |v * sc| < 2^10: in range; round to nearest even
         }
         *reinterpret_cast<f16x8*>(xh + static_cast<size_t>(row) * H_ROW + c0) = hv;
         if (sub == 0) {
@@ -370,20 +376,22 @@ __global__ __launch_bounds__(256) void knn_l2_prep16g(const float* __restrict__ 
             const f16x8 e1 = {0, 0, 0, 0, 0, 0, 0, 0};
             if (is_t) {
                 if (live) {
-                    // ||S_t t||^2 <= 2^20, kept to 1/16: an integer below 2^24 + 1
-                    const float z = __builtin_rintf(tnorm[row] * gs.st * gs.st * 16.f);
+                    // ||S_t t||^2 < 2^20, kept to 1/16: an integer below 2^24
+                    const float z = __builtin_rintf(nrm[it] * st * st * 16.f);
                     const unsigned tn = z < 16777216.f ? static_cast<unsigned>(z) : 16777215u;
                     e0[0] = static_cast<_Float16>(static_cast<float>(tn >> 13));
                     e0[1] = static_cast<_Float16>(static_cast<float>((tn >> 6) & 127u));
                     e0[2] = static_cast<_Float16>(static_cast<float>(tn & 63u));
                 } else {
-                    e0[0] = static_cast<_Float16>(60000.f);  // pad row: w = -1.55e7 r, below every real row (>= -2^20 - 2^19 r)
+                    e0[0] = static_cast<_Float16>(60000.f);  // pad row: w = -1.55e7 2^j, below every real row (>= -2^20 - 2^19 2^j)
                     e0[1] = static_cast<_Float16>(60000.f);
                 }
+            } else if (live && qs.unranked) {
+                e0[0] = static_cast<_Float16>(__builtin_nanf(""));    // every value of this query is NaN: nothing is ranked
             } else {
-                e0[0] = static_cast<_Float16>(gs.qc[0]);
-                e0[1] = static_cast<_Float16>(gs.qc[1]);
-                e0[2] = static_cast<_Float16>(gs.qc[2]);
+                e0[0] = static_cast<_Float16>(qs.qc[0]);
+                e0[1] = static_cast<_Float16>(qs.qc[1]);
+                e0[2] = static_cast<_Float16>(qs.qc[2]);
             }
             *reinterpret_cast<f16x8*>(xh + static_cast<size_t>(row) * H_ROW + H_DP) = e0;
             *reinterpret_cast<f16x8*>(xh + static_cast<size_t>(row) * H_ROW + H_DP + 8) = e1;
@@ -542,12 +550,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void knn_
     const bool nonfinite = (flagged && (s1 & 1ull)) || (route == ROUTE_F16_HINT && ineligible);
     const KnnGeom g = use16 ? g16 : g32;
     float unscale = 1.f, eps_c = g.eps_coef, eps_abs = 0.f;
+    bool unranked = false;
     if constexpr (GEN) {
         if (general) {
-            const GenScales gs = gen_scales(s0, stats[2], epoch);
-            unscale = gs.unscale;
+            const QueryScale qs = query_scale(train_half_exp(s0, epoch), na);
+            unscale = qs.unscale;
             eps_c = g.eps_coef_gen;
-            eps_abs = g.abs_gen * gs.unscale;
+            eps_abs = g.abs_gen * qs.unscale;
+            unranked = qs.unranked;
         }
     }
     if (diag && lane == 0 && !ghost && q == 0) diag[2] = general ? 1u : (use16 ? 0u : 2u);
@@ -590,7 +600,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void knn_
     const float thr = (tau + eps) * 1.00000095367431640625f + eps;
 
     // Non-finite inputs (or a window that is not finite) void the coarse ranking: scan everything.
-    const bool rescan = nonfinite || !(thr < KNN_INF);
+    const bool rescan = nonfinite || !(thr < KNN_INF) || unranked;
     if (diag && lane == 0 && !ghost) { if (rescan) atomicAdd(&diag[0], 1u); if (nonfinite) diag[1] = 1u; }
 
     Best2 b{~0ull, ~0ull, KNN_INF, KNN_INF};
@@ -994,7 +1004,10 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
         return rx == PM_OK && fuse ? 1 : rx;                 // 1: done, but the caller still has to filter
     }
     const int route = (flags & PM_KNN_FORCE_F32) ? ROUTE_F32 : (flags & PM_KNN_HINT_INTEGER) ? ROUTE_F16_HINT : ROUTE_AUTO;
-    const bool want32 = route != ROUTE_F16_HINT, want16 = route != ROUTE_F32;
+    // automatic route: general floats rank on rounded f16 copies too (SPEC S1c); the f32-input pass is enqueued only when
+    // forced (PM_KNN_FORCE_F32) or when PM_OPT_KNN_GENERAL_F16 = 1 keeps it as the automatic route's pass for such data
+    const bool gen32 = route == ROUTE_AUTO && ctx->opts[PM_OPT_KNN_GENERAL_F16] == 1;
+    const bool want32 = route == ROUTE_F32 || gen32, want16 = route != ROUTE_F32;
 
     // ---- f32 route geometry: 64-row tiles, 128 queries per workgroup, two workgroups per CU.
     // (A 128-row tile with one workgroup per CU measured 172 us against 153 us at C3.)
@@ -1106,16 +1119,16 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
         pm::ScopedKernelTime t(ctx, "knn_l2_prep");
         if (want16)
             hipLaunchKernelGGL(knn_l2_prep16, dim3(nq_pad / 64 + nt_pad / 64), dim3(256), 0, ctx->stream, dq, nq, nq_pad,
-                               dt, nt, nt_pad, dim, qnorm, tnorm, Qh, Th, stats, epoch, route == ROUTE_AUTO ? 1 : 0);
+                               dt, nt, nt_pad, dim, qnorm, tnorm, Qh, Th, stats, epoch);
         else
             hipLaunchKernelGGL(knn_l2_prep, dim3((nq + 63) / 64 + (nt + 63) / 64), dim3(256), 0, ctx->stream, dq, nq, dt,
                                nt, dim, qnorm, tnorm, stats, epoch);
-        // automatic route: data that failed the integer premise get f16-ROUNDED scaled copies instead (the scales need the
-        // norm maxima of the pass above, hence a launch of its own; it returns at once for integer data)
-        if (route == ROUTE_AUTO && ctx->opts[PM_OPT_KNN_GENERAL_F16] != 1)
+        // automatic route: data that failed the integer premise get f16-ROUNDED scaled copies instead (the train scale
+        // needs the norm maximum of the pass above, hence a launch of its own; it returns at once for integer data)
+        if (route == ROUTE_AUTO && !gen32)
             hipLaunchKernelGGL(knn_l2_prep16g, dim3(nq_pad / 64 + nt_pad / 64), dim3(256), 0, ctx->stream, dq, nq, nq_pad, dt,
-                               nt, nt_pad, dim, tnorm, Qh, Th, stats, epoch);
-        else if (route == ROUTE_AUTO)
+                               nt, nt_pad, dim, qnorm, tnorm, Qh, Th, stats, epoch);
+        else if (gen32)
             hipLaunchKernelGGL(knn_gen_off, dim3(1), dim3(64), 0, ctx->stream, stats, epoch);
         PM_HIP_CHECK(hipGetLastError());
     }

@@ -330,29 +330,43 @@ def test_general_floats_take_the_rounded_f16_pass(ctx, oracle, nq, nt, dim):
     assert sti["route"] == 0
 
 
-def test_general_floats_scales_and_withdrawal(ctx, oracle):
-    """The rounded-copy route rescales by powers of two and withdraws to the f32-input pass when the two matrices'
-    scales are too far apart or an input is not finite; whatever it does, the result is the canonical one."""
+def test_general_floats_scales(ctx, oracle):
+    """The rounded-copy route rescales by powers of two — the train matrix by one factor, every query row by its own —
+    so it covers any pair of scales: tiny queries lose bits (wider window, at worst re-scans), queries more than 8x
+    larger than every train row are not ranked at all (exact scan of that query).  Whatever it does, the result is
+    the canonical one; a non-finite input sends every query to the exact scan."""
     q, t, _ = synth.surf_like(300, 2000, 128, seed=77)
-    cases = [("tiny", q * np.float32(1e-12), t * np.float32(1e-12), 1),
-             ("huge", q * np.float32(3e15), t * np.float32(3e15), 1),
-             ("train x64", q, t * np.float32(64.0), 1),
-             ("query x1000 (ratio out of range)", q * np.float32(1000.0), t, 2),
-             ("train x1e4 (ratio out of range)", q, t * np.float32(1e4), 2)]
-    t_out = t.copy(); t_out[17] *= np.float32(50.0)              # one large row sets the train scale (r = 2^6) ...
-    cases.append(("one large train row", q, t_out, 1))
-    t_out = t.copy(); t_out[17] *= np.float32(5000.0)            # ... a giant one pushes r out of range
-    cases.append(("one giant train row", q, t_out, 2))
+    cases = [("tiny", q * np.float32(1e-12), t * np.float32(1e-12)),
+             ("huge", q * np.float32(3e15), t * np.float32(3e15)),
+             ("train x64", q, t * np.float32(64.0)),
+             ("train x1e4 (queries 2^-13 of the train scale)", q, t * np.float32(1e4)),
+             ("query x6", q * np.float32(6.0), t)]
+    t_out = t.copy(); t_out[17] *= np.float32(50.0)              # one large row sets the train scale
+    cases.append(("one large train row", q, t_out))
+    t_out = t.copy(); t_out[17] *= np.float32(5000.0)
+    cases.append(("one giant train row", q, t_out))
     q_mix = q.copy(); q_mix[::2] *= np.float32(1e-4)
-    cases.append(("queries of mixed scale", q_mix, t, 1))
-    for name, qq, tt, route in cases:
+    cases.append(("queries of mixed scale", q_mix, t))
+    for name, qq, tt in cases:
         got, st = _route_of(ctx, qq, tt)
-        assert st["route"] == route, (name, st)
+        assert st["route"] == 1 and st["nonfinite"] == 0, (name, st)
         assert_matches_equal(got, oracle.bf_knn_l2(qq, tt, 2, nthreads=8), name)
+    # queries far above the train scale have no f16 image: each of them is scanned exactly
+    qq = q.copy(); qq[:40] *= np.float32(1000.0)
+    got, st = _route_of(ctx, qq, t)
+    assert st["route"] == 1 and st["rescans"] >= 40, st
+    assert_matches_equal(got, oracle.bf_knn_l2(qq, t, 2, nthreads=8), "40 queries x1000")
     t_nan = t.copy(); t_nan[5, 3] = np.inf
     got, st = _route_of(ctx, q, t_nan)
     assert st["nonfinite"] == 1
     assert_matches_equal(got, oracle.bf_knn_l2(q, t_nan, 2, nthreads=8), "non-finite input")
+    try:                                                          # the f32-input pass stays selectable
+        ctx.set_option(pm.api.PM_OPT_KNN_GENERAL_F16, 1)
+        got, st = _route_of(ctx, q, t * np.float32(1e4))
+        assert st["route"] == 2
+        assert_matches_equal(got, oracle.bf_knn_l2(q, t * np.float32(1e4), 2, nthreads=8), "f32-input pass")
+    finally:
+        ctx.set_option(pm.api.PM_OPT_KNN_GENERAL_F16, 0)
 
 
 def test_general_floats_near_ties_below_f16_resolution(ctx, oracle):
