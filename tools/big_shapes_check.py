@@ -28,3 +28,14 @@ g = ctx.ransac_fundamental(x1, x2, 3000, 1.0, 5)
 w = O.ransac_fundamental(x1, x2, 3000, 1.0, 5, nthreads=16)
 assert g[0] == w[0] and g[4] == w[4] and (g[2] == w[2]).all() and (g[1].view(np.uint64) == w[1].view(np.uint64)).all()
 print("ransac n=30000 ok", g[3])
+if "huge" in sys.argv:
+    # a train copy beyond 2 GiB (7.6 M rows x 288 B): the coarse kernel's LDS-DMA addresses it through a buffer descriptor
+    # with 32-bit offsets, so such sizes fall back to register staging — same result
+    nq, nt = 64, 7_600_000
+    t = rng.integers(0, 120, size=(nt, 128), dtype=np.uint8).astype(np.float32)
+    q = t[rng.integers(0, nt, size=nq)].copy()
+    q[:, ::7] += 3.0
+    t0 = time.time(); got = ctx.bf_knn_l2(q, t, 2, 4); t1 = time.time()
+    want = O.bf_knn_l2(q, t, 2, nthreads=16)
+    assert_matches_equal(got, want, "huge nt")
+    print("L2", nq, nt, "huge ok", round(t1 - t0, 3), "s incl. copies")
