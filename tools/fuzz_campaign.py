@@ -22,7 +22,7 @@ ctx = pm.Context(0)
 A = pm.api
 rng = np.random.default_rng(seed)
 t_end = time.time() + budget
-counts = {"l2": 0, "hamming": 0, "ransac": 0, "lmeds": 0, "mgpu": 0}
+counts = {"l2": 0, "hamming": 0, "ransac": 0, "lmeds": 0}
 NT = 16
 
 
@@ -140,7 +140,55 @@ def lmeds_case(i):
     assert np.float64(got[5]).view(np.uint64) == np.float64(want[5]).view(np.uint64), what
 
 
-cases = [("l2", l2_case, 0.45), ("hamming", hamming_case, 0.2), ("ransac", ransac_case, 0.25), ("lmeds", lmeds_case, 0.1)]
+def pipeline_case(i):
+    """pm_bf_knn_l2_ratio_dev (matcher + ratio + compaction + gather, fused or as two launches) feeding the one-call
+    RANSAC run on device buffers: survivors, points, winner and mask against the oracle's chain."""
+    import torch
+    dev = torch.device("cuda", 0)
+    dim = int(rng.choice([32, 64, 128, 128]))
+    nq = int(rng.integers(8, 3000)); nt = int(rng.integers(2, 4000))
+    kind = str(rng.choice(["sift", "surf"]))
+    w = synth.pair_workload(nq, nt, dim, seed=int(rng.integers(1 << 30)), planted=float(rng.uniform(0.05, 0.6)), kind=kind)
+    flags = int(rng.choice([0, A.PM_KNN_HINT_INTEGER])) if kind == "sift" else 0
+    ratio = float(rng.choice([0.6, 0.8, 0.95]))
+    mode = int(rng.integers(0, 3)); with_knn = bool(rng.integers(0, 2)) or mode == 1
+    H = int(rng.integers(1, 1500))
+    d_q, d_t = torch.from_numpy(w["q"]).to(dev), torch.from_numpy(w["t"]).to(dev)
+    d_kp1, d_kp2 = torch.from_numpy(w["kp1"]).to(dev), torch.from_numpy(w["kp2"]).to(dev)
+    d_knn = torch.zeros((nq, 2, 4), dtype=torch.int32, device=dev)
+    d_good = torch.full((nq, 4), -7, dtype=torch.int32, device=dev)
+    d_xy1 = torch.full((nq, 2), -1.0, dtype=torch.float32, device=dev)
+    d_xy2 = torch.full((nq, 2), -1.0, dtype=torch.float32, device=dev)
+    d_n = torch.full((1,), -1, dtype=torch.int32, device=dev)
+    d_key = torch.zeros(1, dtype=torch.int64, device=dev); d_F = torch.zeros(9, dtype=torch.float64, device=dev)
+    d_mask = torch.zeros(nq, dtype=torch.uint8, device=dev); d_ninl = torch.zeros(1, dtype=torch.int32, device=dev)
+    what = "pipeline case %d: %s %dx%dx%d flags=%d ratio=%g fusion=%d knn=%d H=%d" % (i, kind, nq, nt, dim, flags, ratio, mode, with_knn, H)
+    try:
+        ctx.set_option(A.PM_OPT_FILTER_FUSION, mode)
+        ctx.bf_knn_l2_ratio_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, flags, ratio, d_kp1.data_ptr(), d_kp2.data_ptr(),
+                                d_knn.data_ptr() if with_knn else 0, d_good.data_ptr(), d_xy1.data_ptr(), d_xy2.data_ptr(),
+                                d_n.data_ptr())
+        ctx.ransac_run_dev(d_xy1.data_ptr(), d_xy2.data_ptr(), nq, d_n.data_ptr(), 0, H, 1.0, 99 + i, d_key.data_ptr(),
+                           d_F.data_ptr(), d_mask.data_ptr(), d_ninl.data_ptr())
+        ctx.synchronize()
+    finally:
+        ctx.set_option(A.PM_OPT_FILTER_FUSION, 0)
+    want = O.filter_ratio(O.bf_knn_l2(w["q"], w["t"], 2, nthreads=NT), ratio)
+    n = int(d_n.item())
+    assert n == want.size, (what, n, want.size)
+    assert_matches_equal(d_good.cpu().numpy().view(pm.MATCH_DTYPE).reshape(-1)[:n], want, what)
+    x1, x2 = w["kp1"][want["queryIdx"]], w["kp2"][want["trainIdx"]]
+    assert (d_xy1.cpu().numpy()[:n] == x1).all() and (d_xy2.cpu().numpy()[:n] == x2).all(), what
+    rw = O.ransac_fundamental(x1, x2, H, 1.0, 99 + i, nthreads=NT)
+    assert int(d_key.item()) == (rw[4] if rw[4] < (1 << 63) else rw[4] - (1 << 64)), (what, int(d_key.item()), rw[4])
+    if n >= 8:
+        assert int(d_ninl.item()) == rw[3] and (d_mask.cpu().numpy()[:n] == rw[2]).all(), what
+        assert (d_F.cpu().numpy().view(np.uint64) == rw[1].reshape(9).view(np.uint64)).all(), what
+
+
+counts["pipeline"] = 0
+cases = [("l2", l2_case, 0.4), ("hamming", hamming_case, 0.18), ("ransac", ransac_case, 0.22), ("lmeds", lmeds_case, 0.08),
+         ("pipeline", pipeline_case, 0.12)]
 i = 0
 last = time.time()
 while time.time() < t_end:
