@@ -33,6 +33,7 @@ typedef Abl<false, false, false, false> AblNone;
 // 8 * (Q/a + T/b) over a*b = 8 for Q = T).  Measured (profiles/r02_pmc_*): C3 f16 fetch 21.3 -> 14.4 MB, C4 i8 76.4 ->
 // 50.8 MB; same-session A/B of the two orders (PM_OPT_KNN_XCD_TILE 1 / 2): tiled is 0-4 % faster at every shape tried
 // (C3 f16 19.85 -> 19.61 us, C3 f32 route 147.1 -> 141.7, C4 i8 198.9 -> 196.2, 32k x 32k f16 211.4 -> 209.0).
+// (The mapping is a bijection of the grid whatever the number of XCDs: on a partitioned device it is merely not useful.)
 struct WgTile { int qb, split; };
 __device__ __forceinline__ WgTile wg_tile(bool tiled)
 {
@@ -669,11 +670,7 @@ __global__ __launch_bounds__(H_QB / (32 * NQB) * 64 * GR, (NQB == 2 ? 2 : 4)) vo
 }
 
 // PM_OPT_KNN_XCD_TILE: 1 = launch order, 2 = tiled (the default; wg_tile falls back when the grid shape does not divide)
-inline bool xcd_tiled(const pm_ctx* ctx, long long workgroups)
-{
-    (void)workgroups;
-    return ctx->opts[PM_OPT_KNN_XCD_TILE] != 1;
-}
+inline bool xcd_tiled(const pm_ctx* ctx) { return ctx->opts[PM_OPT_KNN_XCD_TILE] != 1; }
 
 template <int NCH, bool FULL, int TT, typename ABL>
 int launch_mfma(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt, int dim, const float* tnorm, int splits,
@@ -691,7 +688,7 @@ int launch_mfma(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt, i
     }
     dim3 grid((nq + QB - 1) / QB, splits);
     // a grid that is resident at once takes the XCD-tiled workgroup order (see wg_tile)
-    const int mode = (only_if_ineligible ? 1 : 0) | (xcd_tiled(ctx, static_cast<long long>(grid.x) * grid.y) ? 2 : 0);
+    const int mode = (only_if_ineligible ? 1 : 0) | (xcd_tiled(ctx) ? 2 : 0);
     pm::ScopedKernelTime t(ctx, "knn_l2_mfma");
     hipLaunchKernelGGL((knn_l2_mfma<NCH, FULL, TT, ABL>), grid, dim3(256), lds, ctx->stream, dq, dt, tnorm, nq, nt, dim,
                        tiles_per_split, keep_mask, cval, slots, stats, epoch, mode);
@@ -748,7 +745,7 @@ int launch_rows288(pm_ctx* ctx, const char* name, const void* Qh, const void* Th
 #define PM_GO(NQB_, DMA_, GR_, THREADS_)                                                                           \
     hipLaunchKernelGGL((knn_mfma_rows288<R, NQB_, DMA_, GR_, ABL>), dim3(nq_pad / H_QB, splits), dim3(THREADS_), lds,  \
                        ctx->stream, q4, t4, nq, nt, tiles_per_split, par, out, slots, stats, epoch, mode)
-    mode = (mode ? 1 : 0) | (xcd_tiled(ctx, static_cast<long long>(nq_pad / H_QB) * splits) ? 2 : 0);     // see wg_tile
+    mode = (mode ? 1 : 0) | (xcd_tiled(ctx) ? 2 : 0);     // see wg_tile
     bool grouped = false;
     if constexpr (R::MERGE) {
         if (nqb == 3) {
