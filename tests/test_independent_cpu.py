@@ -6,8 +6,10 @@ consistent transcription, not correctness.  Here the oracle is checked against D
   * the division-free fp32 Sampson / symmetric-epipolar predicates (S8) against a float64 evaluation of the textbook
     formulas, away from the threshold;
   * the canonical fp32 squared distance (S1) against math.fsum within its a-priori error bound;
-  * the sampler (S6) for uniformity.
-GPU twins of the first two live in tests/test_independent_gpu.py."""
+  * the sampler (S6) for uniformity;
+  * the matcher's definition of "nearest" (S1-S3) against scikit-learn's brute-force neighbours (another code base,
+    float64 GEMM-expansion distances; Hamming on unpacked bits), indices wherever neighbours are not tied.
+GPU twins live in tests/test_independent_gpu.py."""
 import math
 
 import numpy as np
@@ -128,3 +130,53 @@ def test_sampler_is_uniform_and_distinct(oracle):
     exp = 20000 * 8 / n
     chi2 = ((counts - exp) ** 2 / exp).sum()
     assert chi2 < 170                                # 96 degrees of freedom: P(chi2 > 170) ~ 5e-6
+
+
+def sklearn_knn(q, t, k, metric="euclidean"):
+    """Brute-force k-NN by scikit-learn: a different code base and a different arithmetic (float64 GEMM expansion
+    ||x||^2 + ||y||^2 - 2 x.y for 'euclidean', per-element mismatch fraction for 'hamming')."""
+    from sklearn.neighbors import NearestNeighbors
+    nn = NearestNeighbors(n_neighbors=k, algorithm="brute", metric=metric).fit(t)
+    return nn.kneighbors(q)
+
+
+def check_knn_against_sklearn(got, q, t, k, what):
+    """Indices must agree wherever sklearn's own float64 distances separate neighbour j from j+1 by more than the fp32
+    error of either side; distances within the a-priori bound of SPEC S1 (sqrt of a sum with (dim + 2) roundings)."""
+    d_sk, i_sk = sklearn_knn(q.astype(np.float64), t.astype(np.float64), min(k + 1, t.shape[0]))
+    dim = q.shape[1]
+    scale = np.sqrt((q.astype(np.float64) ** 2).sum(1))[:, None] + np.sqrt((t.astype(np.float64) ** 2).sum(1)).max()
+    tol = 64.0 * (dim + 8) * 2.0 ** -24 * scale            # generous: covers sklearn's cancellation as well
+    kk = min(k, t.shape[0])
+    assert np.all(np.abs(got["distance"][:, :kk].astype(np.float64) - d_sk[:, :kk]) <= tol), what
+    for j in range(kk):
+        # neighbour j is unambiguous when it is clear of both its neighbours in the sorted list
+        lo = d_sk[:, j] - (d_sk[:, j - 1] if j > 0 else -np.inf) > 4 * tol[:, 0]
+        hi = (d_sk[:, j + 1] if j + 1 < d_sk.shape[1] else np.inf) - d_sk[:, j] > 4 * tol[:, 0]
+        clear = lo & hi
+        assert clear.mean() > 0.5, (what, j, clear.mean())
+        assert (got["trainIdx"][clear, j] == i_sk[clear, j]).all(), (what, j)
+
+
+@pytest.mark.parametrize("kind", ["sift", "surf"])
+def test_oracle_knn_agrees_with_scikit_learn(oracle, kind):
+    """SPEC S1/S3 (what the oracle defines as THE result) against scikit-learn's brute-force neighbours."""
+    from points_matching_amd import synth
+    q, t, _ = (synth.sift_like if kind == "sift" else synth.surf_like)(400, 1500, 128, seed=17)
+    check_knn_against_sklearn(oracle.bf_knn_l2(q, t, 2), q, t, 2, kind)
+
+
+def test_oracle_hamming_agrees_with_scikit_learn(oracle):
+    """SPEC S2/S3: Hamming distances are integers, so scikit-learn ('hamming' on the unpacked bits = mismatching
+    fraction) must reproduce them exactly, and the indices wherever the k-th and (k+1)-th distances differ."""
+    from points_matching_amd import synth
+    q, t, _ = synth.orb_like(300, 1200, 32, seed=23)
+    got = oracle.bf_knn_hamming(q, t, 2)
+    qb, tb = np.unpackbits(q, axis=1).astype(np.float64), np.unpackbits(t, axis=1).astype(np.float64)
+    d_sk, i_sk = sklearn_knn(qb, tb, 3, metric="hamming")
+    d_sk = np.rint(d_sk * 256.0)
+    assert (got["distance"] == d_sk[:, :2]).all()
+    for j in range(2):
+        clear = (d_sk[:, j + 1] > d_sk[:, j]) & ((j == 0) | (d_sk[:, j] > d_sk[:, j - 1]))
+        assert clear.mean() > 0.5
+        assert (got["trainIdx"][clear, j] == i_sk[clear, j]).all()

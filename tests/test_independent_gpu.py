@@ -45,3 +45,25 @@ def test_hip_winner_is_the_best_model_by_an_independent_count(ctx):
         rc_h, F_h, mask_h, n_h = ctx.ransac_model_from_hyp(x1, x2, h, 1.0, 42)
         s_h, _ = _sampson64(F_h.astype(np.float32).astype(np.float64), x1, x2)
         assert int((s_h <= 1.0).sum()) <= ninl + border + int((np.abs(s_h - 1.0) <= 1e-3).sum()), h
+
+
+@pytest.mark.parametrize("kind,flags", [("sift", 0), ("sift", 4), ("surf", 0), ("surf", 2)])
+def test_hip_knn_agrees_with_scikit_learn(ctx, kind, flags):
+    """The HIP matcher (integer route, hinted route, general-float route, f32-input route) against scikit-learn's
+    brute-force neighbours — not against the oracle.  Slot: matcher.match, main.cpp:46."""
+    from test_independent_cpu import check_knn_against_sklearn
+    q, t, _ = (synth.sift_like if kind == "sift" else synth.surf_like)(600, 3000, 128, seed=29)
+    check_knn_against_sklearn(ctx.bf_knn_l2(q, t, 2, flags), q, t, 2, "%s flags %d" % (kind, flags))
+
+
+def test_hip_hamming_agrees_with_scikit_learn(ctx):
+    from test_independent_cpu import sklearn_knn
+    q, t, _ = synth.orb_like(500, 2500, 32, seed=31)
+    got = ctx.bf_knn_hamming(q, t, 2)
+    qb, tb = np.unpackbits(q, axis=1).astype(np.float64), np.unpackbits(t, axis=1).astype(np.float64)
+    d_sk, i_sk = sklearn_knn(qb, tb, 3, metric="hamming")
+    d_sk = np.rint(d_sk * 256.0)
+    assert (got["distance"] == d_sk[:, :2]).all()
+    for j in range(2):
+        clear = (d_sk[:, j + 1] > d_sk[:, j]) & ((j == 0) | (d_sk[:, j] > d_sk[:, j - 1]))
+        assert (got["trainIdx"][clear, j] == i_sk[clear, j]).all()
