@@ -7,6 +7,8 @@ consistent transcription, not correctness.  Here the oracle is checked against D
     formulas, away from the threshold;
   * the canonical fp32 squared distance (S1) against math.fsum within its a-priori error bound;
   * the sampler (S6) for uniformity;
+  * the 7-point solver (S14: QR null space, bisection + deflation of the cubic) against numpy's SVD null space +
+    np.roots on 600 random minimal samples;
   * the matcher's definition of "nearest" (S1-S3) against scikit-learn's brute-force neighbours (another code base,
     float64 GEMM-expansion distances; Hamming on unpacked bits), indices wherever neighbours are not tied.
 GPU twins live in tests/test_independent_gpu.py."""
@@ -180,3 +182,69 @@ def test_oracle_hamming_agrees_with_scikit_learn(oracle):
         clear = (d_sk[:, j + 1] > d_sk[:, j]) & ((j == 0) | (d_sk[:, j] > d_sk[:, j - 1]))
         assert clear.mean() > 0.5
         assert (got["trainIdx"][clear, j] == i_sk[clear, j]).all()
+
+
+def np_seven_point(p1, p2):
+    """Textbook 7-point with numpy: Hartley normalisation, null space of the 7 x 9 system by LAPACK SVD, the cubic
+    det(a F1 + (1 - a) F2) = 0 by polynomial interpolation + np.roots.  Returns the real solutions, each with unit
+    Frobenius norm and F[2,2] >= 0."""
+    def hartley(p):
+        c = p.mean(axis=0)
+        md = np.sqrt(((p - c) ** 2).sum(axis=1)).mean()
+        s = math.sqrt(2.0) / md
+        T = np.array([[s, 0, -s * c[0]], [0, s, -s * c[1]], [0, 0, 1.0]])
+        return (p - c) * s, T
+    a, T1 = hartley(p1)
+    b, T2 = hartley(p2)
+    A = np.stack([b[:, 0] * a[:, 0], b[:, 0] * a[:, 1], b[:, 0], b[:, 1] * a[:, 0], b[:, 1] * a[:, 1], b[:, 1],
+                  a[:, 0], a[:, 1], np.ones(7)], axis=1)
+    _, sv, Vt = np.linalg.svd(A)
+    F1, F2 = Vt[-1].reshape(3, 3), Vt[-2].reshape(3, 3)
+    xs = np.array([-1.0, 0.0, 1.0, 2.0])
+    ys = np.array([np.linalg.det(x * F1 + (1 - x) * F2) for x in xs])
+    coef = np.polyfit(xs, ys, 3)
+    out = []
+    for r in np.roots(coef):
+        if abs(r.imag) > 1e-9 * max(1.0, abs(r.real)):
+            continue
+        Fn = r.real * F1 + (1 - r.real) * F2
+        F = T2.T @ Fn @ T1
+        F /= np.linalg.norm(F)
+        if F[2, 2] < 0:
+            F = -F
+        out.append(F)
+    return out, sv
+
+
+def test_seven_point_solver_agrees_with_numpy(oracle):
+    """SPEC S14 (QR null space, bisection + deflation of the cubic) against numpy's SVD null space + np.roots: every
+    model the oracle returns is one of numpy's solutions, and well-separated numpy solutions are all found."""
+    from points_matching_amd import synth
+    x1, x2, _, _ = synth.two_view(700, seed=41, outlier_frac=0.2, noise_px=0.6)
+    rng = np.random.default_rng(43)
+    checked, worst = 0, 0.0
+    for _ in range(600):
+        idx = rng.choice(700, size=7, replace=False)
+        p1, p2 = x1[idx].astype(np.float64), x2[idx].astype(np.float64)
+        Fo, valid = oracle.solve7(p1, p2)
+        sols, sv = np_seven_point(p1, p2)
+        if sv[6] / sv[0] < 1e-6 or not sols:           # (near-)degenerate sample: the null space itself is ill-defined
+            continue
+        mine = [Fo[r] for r in range(3) if valid[r]]
+        assert mine, "no model for a regular sample"
+        for F in mine:                                 # each returned model is a solution
+            err = min(min(np.linalg.norm(F - G), np.linalg.norm(F + G)) for G in sols)
+            # conditioning of a root: closeness of two solutions degrades both; scale the bound by it
+            sep = min([np.linalg.norm(G - H) for gi, G in enumerate(sols) for H in sols[gi + 1:]] + [1.0])
+            assert err <= 1e-9 / max(sep, 1e-6) + 1e-11, (err, sep)
+            worst = max(worst, err)
+            # and it satisfies the 7 epipolar constraints and det F = 0
+            h1 = np.c_[p1, np.ones(7)]; h2 = np.c_[p2, np.ones(7)]
+            # (the repo's convention, docs/SPEC.md S7: x2^T F x1 = 0)
+            res = np.abs(np.einsum("ij,jk,ik->i", h2, F, h1))
+            scale = np.linalg.norm(h1, axis=1) * np.linalg.norm(h2, axis=1)
+            assert (res <= 1e-9 * scale).all() and abs(np.linalg.det(F)) <= 1e-12
+        if len(sols) == len(mine) or all(np.linalg.norm(G - H) > 1e-3 for gi, G in enumerate(sols) for H in sols[gi + 1:]):
+            assert len(mine) == len(sols), (len(mine), len(sols))
+        checked += 1
+    assert checked >= 500 and worst < 1e-8

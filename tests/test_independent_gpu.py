@@ -67,3 +67,24 @@ def test_hip_hamming_agrees_with_scikit_learn(ctx):
     for j in range(2):
         clear = (d_sk[:, j + 1] > d_sk[:, j]) & ((j == 0) | (d_sk[:, j] > d_sk[:, j - 1]))
         assert (got["trainIdx"][clear, j] == i_sk[clear, j]).all()
+
+
+def test_hip_lmeds_winner_is_a_numpy_seven_point_solution(ctx, oracle):
+    """7-point + LMedS on the device (SPEC S13-S15): the F it returns is one of numpy's (SVD null space + np.roots)
+    solutions for the seven correspondences its winning id samples.  Slot: findFundamentalMat(CV_FM_7POINT)."""
+    from points_matching_amd.api import lmeds_fundamental
+    from test_independent_cpu import np_seven_point
+    checked = 0
+    for s in range(12):
+        x1, x2, _, _ = synth.two_view(600 + 50 * s, seed=100 + s, outlier_frac=0.3, noise_px=0.5)
+        rc, F, mask, ninl, best, med = lmeds_fundamental(ctx, x1, x2, 300, 9 + s)
+        assert rc == 0 and best >= 0
+        idx = oracle.sample7(9 + s, best // 3, x1.shape[0])
+        sols, sv = np_seven_point(x1[idx].astype(np.float64), x2[idx].astype(np.float64))
+        if sv[6] / sv[0] < 1e-6:
+            continue
+        err = min(min(np.linalg.norm(F - G), np.linalg.norm(F + G)) for G in sols)
+        sep = min([np.linalg.norm(G - H) for gi, G in enumerate(sols) for H in sols[gi + 1:]] + [1.0])
+        assert err <= 1e-9 / max(sep, 1e-6) + 1e-11, (s, err, sep)
+        checked += 1
+    assert checked >= 10
