@@ -289,7 +289,10 @@ def main():
     # One contiguous "survivor block" per rank: [count (int32) + 3 pad words | xy1: nq x 2 f32 | xy2: nq x 2 f32].
     # The filter writes straight into it, so the N>1 exchange before RANSAC is ONE all-gather of this block and
     # RANSAC reads the gathered blocks through a pm_points_view (no concatenation pass).
-    d_blk, d_n, d_xy1, d_xy2 = shard.survivor_block(nq, dev)
+    # (N>1: the block is this rank's row of the gathered buffer and the record this rank's row of the gathered records,
+    # so both all-gathers run in place: no send-side copy)
+    g_blk = shard.gathered_blocks(world, nq, dev) if multi else None
+    d_blk, d_n, d_xy1, d_xy2 = shard.survivor_block(nq, dev, into=g_blk[rank] if multi else None)
     d_key = torch.zeros(1, dtype=torch.int64, device=dev)
     n_all_max = nq * world
     d_F = torch.zeros(9, dtype=torch.float64, device=dev)
@@ -297,9 +300,8 @@ def main():
     d_ninl = torch.zeros(1, dtype=torch.int32, device=dev)
     d_ntot = torch.zeros(1, dtype=torch.int32, device=dev)
     if multi:
-        g_blk = torch.zeros((world, d_blk.numel()), dtype=torch.float32, device=dev)
-        d_rec = torch.zeros(10, dtype=torch.float64, device=dev)             # pm_ransac_record: key + F[9]
         g_rec = torch.zeros((world, 10), dtype=torch.float64, device=dev)
+        d_rec = g_rec[rank]                                                  # pm_ransac_record: key + F[9]
         view = shard.view_of_blocks(g_blk, nq)
     hb, he = shard.hyp_shard(H, rank, world)
 

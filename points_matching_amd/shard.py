@@ -35,11 +35,18 @@ def pair_shard(n_pairs, rank, world):
     return list(range(rank, n_pairs, world))
 
 
-def survivor_block(cap, device):
+def survivor_block(cap, device, into=None):
     """One rank's survivor block and the views the filter writes through: (block f32[4 + 4*cap], n int32[1],
-    xy1 f32[cap, 2], xy2 f32[cap, 2])."""
-    blk = torch.zeros(4 + 4 * cap, dtype=torch.float32, device=device)
+    xy1 f32[cap, 2], xy2 f32[cap, 2]).  `into`: a row of the gathered buffer (`gathered_blocks(...)[rank]`) — the
+    filter then writes where the all-gather expects this rank's contribution and the collective runs in place."""
+    blk = torch.zeros(4 + 4 * cap, dtype=torch.float32, device=device) if into is None else into
+    assert blk.numel() == 4 + 4 * cap and blk.is_contiguous()
     return blk, blk[0:1].view(torch.int32), blk[4:4 + 2 * cap].view(cap, 2), blk[4 + 2 * cap:].view(cap, 2)
+
+
+def gathered_blocks(world, cap, device):
+    """Receive buffer of exchange 1: f32[world, 4 + 4*cap]."""
+    return torch.zeros((world, 4 + 4 * cap), dtype=torch.float32, device=device)
 
 
 def view_of_blocks(g_blk, cap):

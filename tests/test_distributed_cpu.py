@@ -27,11 +27,11 @@ def _worker(rank, world, port, q):
         knn = O.bf_knn_l2(w["q"], w["t"], 2)
         good = O.filter_ratio(knn, 0.8)
         # exchange 1: the survivor block (count | xy1 | xy2), one all-gather
-        blk, n, xy1, xy2 = shard.survivor_block(nq, "cpu")
+        g_blk = shard.gathered_blocks(world, nq, "cpu")
+        blk, n, xy1, xy2 = shard.survivor_block(nq, "cpu", into=g_blk[rank])      # in place, as bench.py runs it
         n[0] = good.size
         xy1[:good.size] = torch.from_numpy(O.gather_points(w["kp1"], good["queryIdx"]))
         xy2[:good.size] = torch.from_numpy(O.gather_points(w["kp2"], good["trainIdx"]))
-        g_blk = torch.zeros((world, blk.numel()), dtype=torch.float32)
         dist.all_gather_into_tensor(g_blk.view(-1), blk)
         a1, a2, cnt = shard.concat_blocks(g_blk, nq)
         view = shard.view_of_blocks(g_blk, nq)
