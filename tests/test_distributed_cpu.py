@@ -7,6 +7,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -52,8 +53,10 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_world2_gloo_sharded_path_equals_unsharded():
-    world, port = 2, 29000 + os.getpid() % 2000
+@pytest.mark.parametrize("world", [2, 5])
+def test_gloo_sharded_path_equals_unsharded(world):
+    """world 2, and an odd world size whose hypothesis cuts are uneven (400 ids over 5 ranks, rows 512 per rank)."""
+    port = 29000 + (os.getpid() * 7 + world) % 2000
     ctxmp = mp.get_context("spawn")
     q = ctxmp.Queue()
     procs = [ctxmp.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
@@ -63,11 +66,11 @@ def test_world2_gloo_sharded_path_equals_unsharded():
         p.join(240)
         assert p.exitcode == 0, 'worker failed'
     res = sorted(q.get(timeout=10) for _ in range(world))
-    assert res[0][1] == res[1][1] > 100            # same global correspondence count on both ranks
+    assert all(r[1] == res[0][1] for r in res) and res[0][1] > 100    # same global correspondence count on every rank
     assert all(r[2] and r[3] and r[4] for r in res)  # winner key, model bits, mask and count = the unsharded run's
-    assert res[0][5] == (0, 200) and res[1][5] == (200, 400)
-    assert res[0][6] == res[1][6]                  # identical gathered correspondences, in rank order
-    assert res[0][7] == (2, 512, 4 + 4 * 512)
+    assert [r[5] for r in res] == [(400 * g // world, 400 * (g + 1) // world) for g in range(world)]
+    assert all(r[6] == res[0][6] for r in res)     # identical gathered correspondences, in rank order
+    assert res[0][7] == (world, 512, 4 + 4 * 512)
 
 
 def test_row_shard_partitions():
