@@ -556,8 +556,9 @@ def main():
                            "traffic": pmc_traffic("c3:knn_l2_mfma_f16", nq, nt),
                            "algorithmic_bytes": (nq + nt) * dim * 4 + nq * K * 16,
                            "dtype": "f16-input MFMA, f32 accumulate (v_mfma_f32_32x32x16_f16), exact for u8-valued data",
-                           "note": "launch/prologue-sized at C3: 19.4 us remain with selection, staging, barrier and LDS reads "
-                                   "all removed (ablation, DESIGN.md 2.1); 8.8 us of pure matrix-pipe time"}
+                           "note": "launch/prologue-sized at C3: 16.7-17.0 us of the 19 us (hipEvent) remain with selection, staging, "
+                                   "barrier and LDS operand reads all removed (ablation builds, DESIGN.md 2.1); 9.2 us of that is "
+                                   "the bare chain of 288 MFMAs per wave at the 2.0 GHz the chip holds"}
     elif "knn_l2_mfma" in kern:
         ach = flops / (kern["knn_l2_mfma"] * 1e-6) / 1e12
         out["roofline"] = {"kernel": "knn_l2_mfma", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
