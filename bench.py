@@ -56,7 +56,7 @@ def pmc_traffic(key, nq, nt):
             return None
     except (OSError, ValueError, KeyError):
         return None
-    want = {"c3:knn_l2_mfma_f16": (8192, 8192), "c3_f32:knn_l2_mfma": (8192, 8192), "c4:knn_hamming_mfma_i8": (32768, 32768)}
+    want = {"c3:knn_l2_mfma_f16": (8192, 8192), "c3:knn_l2_mfma_u8": (8192, 8192), "c3:knn_l2_mfma_f16s": (8192, 8192), "c3_f32:knn_l2_mfma": (8192, 8192), "c4:knn_hamming_mfma_i8": (32768, 32768)}
     if key in t and want.get(key) == (nq, nt):
         return t[key]["traffic_bytes"]
     return None
@@ -200,6 +200,9 @@ def main():
     ap.add_argument("--single-device", action="store_true", help="debugging: every rank uses cuda:0")
     ap.add_argument("--ransac-path", type=int, default=0, choices=[0, 1, 2],
                     help="A/B timing: PM_OPT_RANSAC_PATH (0 automatic, 1 solve + score launches, 2 one-launch kernel)")
+    ap.add_argument("--hint", default="u8", choices=["u8", "int", "auto"],
+                    help="SIFT descriptors: what the caller states about them (u8: integers in [0, 255] -> i8 matrix pass; "
+                         "int: integers, |x| <= 361 -> f16 matrix pass; auto: nothing, the device decides)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
@@ -259,7 +262,7 @@ def main():
     ratio, thresh, seed = 0.8, 1.0, 0x5EED
     # A SIFT matcher knows its descriptors are u8-valued floats: state it, so that only the exact
     # f16-MFMA coarse route is enqueued (the claim is verified on the device).  Other kinds: auto.
-    knn_flags = pm.api.PM_KNN_HINT_INTEGER if args.kind == "sift" else 0
+    knn_flags = {"u8": pm.api.PM_KNN_HINT_U8, "int": pm.api.PM_KNN_HINT_INTEGER, "auto": 0}[args.hint] if args.kind == "sift" else 0
     wseed = 0xC4 if hamming else 0xC3
     nq_total = nq
     if args.scaling == "strong" and world > 1:
@@ -398,7 +401,7 @@ def main():
         step()
     fence()
     kern = {}
-    for name in ("knn_l2_prep", "knn_l2_mfma_f16", "knn_l2_mfma", "knn_l2_refine", "knn_hamming_expand",
+    for name in ("knn_l2_prep", "knn_l2_mfma_u8", "knn_l2_mfma_f16s", "knn_l2_mfma_f16", "knn_l2_mfma", "knn_l2_refine", "knn_hamming_expand",
                  "knn_hamming_mfma_i8", "knn_hamming_refine", "knn_hamming", "knn_hamming_merge", "filter_gather", "ransac_solve", "ransac_score",
                  "ransac_select", "ransac_final", "concat_points", "ransac_fused", "ransac_finish"):
         ms, cnt = ctx.timing_get(name)
@@ -513,7 +516,8 @@ def main():
                                   "ORB-%d binary" % (8 * dim) if hamming else "SIFT-%d f32" % dim,
                                   "Hamming" if hamming else "L2", H), "descriptors": args.kind, "k": K,
                    "coarse_route": "n/a (Hamming)" if hamming else
-                                   "f16-MFMA (integer hint, device-verified)" if knn_flags else "auto"},
+                                   {pm.api.PM_KNN_HINT_U8: "i8-MFMA on x - 128 (u8 hint, device-verified)",
+                                    pm.api.PM_KNN_HINT_INTEGER: "f16-MFMA (integer hint, device-verified)"}.get(knn_flags, "auto")},
         "stage_ms": {"match": match_ms, "ransac_and_exchange": rest_ms,
                      "note": "hipEvent brackets in a second pass of the same K steps (the events themselves add "
                              "~4-5 us per bracket); ms_per_step is the un-instrumented pass"},
@@ -548,6 +552,22 @@ def main():
         out["roofline"] = {"kernel": "knn_hamming_scan", "bound": "valu-int", "achieved": ach, "peak": 39.3,
                            "unit": "Tlane-op/s", "frac": ach / 39.3, "traffic": None,
                            "dtype": "u32 xor + popcount on the VALU (v_xor_b32, v_bcnt_u32_b32)"}
+    elif "knn_l2_mfma_u8" in kern:
+        ach = flops / (kern["knn_l2_mfma_u8"] * 1e-6) / 1e12
+        out["roofline"] = {"kernel": "knn_l2_mfma_u8 (knn_mfma_rows288<RouteU8>)", "bound": "mfma", "achieved": ach,
+                           "peak": 2 * PEAK_F16_MFMA_TFLOPS, "unit": "TOP/s", "frac": ach / (2 * PEAK_F16_MFMA_TFLOPS),
+                           "frac_of_f16_peak": ach / PEAK_F16_MFMA_TFLOPS,
+                           "traffic": pmc_traffic("c3:knn_l2_mfma_u8", nq, nt),
+                           "algorithmic_bytes": (nq + nt) * dim * 4 + nq * K * 16,
+                           "dtype": "i8 x i8 -> i32 MFMA (v_mfma_i32_32x32x32_i8) on x - 128, exact for u8-valued data; every "
+                                    "issued MFMA is algorithmic work (the row term starts the accumulators)"}
+    elif "knn_l2_mfma_f16s" in kern:
+        ach = flops / (kern["knn_l2_mfma_f16s"] * 1e-6) / 1e12
+        out["roofline"] = {"kernel": "knn_l2_mfma_f16s (knn_mfma_rows288<RouteF16S>)", "bound": "mfma", "achieved": ach,
+                           "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F16_MFMA_TFLOPS,
+                           "traffic": pmc_traffic("c3:knn_l2_mfma_f16s", nq, nt),
+                           "algorithmic_bytes": (nq + nt) * dim * 4 + nq * K * 16,
+                           "dtype": "f16-input MFMA, f32 accumulate (v_mfma_f32_32x32x16_f16), exact for integer data"}
     elif kern.get("knn_l2_mfma_f16", 0) > kern.get("knn_l2_mfma", 0):
         ach = flops / (kern["knn_l2_mfma_f16"] * 1e-6) / 1e12
         out["roofline"] = {"kernel": "knn_l2_mfma_f16 (knn_mfma_rows288<RouteF16>)", "bound": "mfma", "achieved": ach,

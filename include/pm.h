@@ -66,7 +66,7 @@ int  pm_ctx_synchronize(pm_ctx* ctx);
 /* Per-kernel timing with hipEvents on the context's stream.  enable!=0 starts collecting.
  * pm_ctx_timing_get: mean milliseconds and launch count of the named kernel since the last
  * pm_ctx_timing_reset (synchronises the stream).  Names: "knn_l2_prep", "knn_l2_mfma_f16",
- * "knn_l2_mfma", "knn_l2_refine", "knn_l2_exact", "knn_hamming_expand", "knn_hamming_mfma_i8",
+ * "knn_l2_mfma", "knn_l2_mfma_u8", "knn_l2_mfma_f16s", "knn_l2_refine", "knn_l2_exact", "knn_hamming_expand", "knn_hamming_mfma_i8",
  * "knn_hamming_refine", "knn_hamming", "knn_hamming_merge", "filter_gather", "concat_points",
  * "ransac_fused", "ransac_finish", "ransac_solve", "ransac_score", "ransac_select", "ransac_final", "lmeds_solve", "lmeds_median",
  * "lmeds_final", "fm_count", "flann_search". */
@@ -79,7 +79,8 @@ int  pm_ctx_timing_get(pm_ctx* ctx, const char* kernel, double* mean_ms, int* la
 int  pm_ctx_knn_diag_enable(pm_ctx* ctx, int enable);
 int  pm_ctx_knn_stats(pm_ctx* ctx, int* rescans, int* nonfinite);
 /* ... and which coarse pass the refinement of the last such call read: 0 = f16 matrix pass on exact integer copies,
- * 1 = f16 matrix pass on rounded copies of general floats, 2 = f32-input matrix pass (synchronises). */
+ * 1 = f16 matrix pass on rounded copies of general floats, 2 = f32-input matrix pass, 3 = i8 matrix pass on centred
+ * u8-valued copies (synchronises). */
 int  pm_ctx_knn_route(pm_ctx* ctx, int* route);
 /* Explicit per-context switches for tests and A/B timing (the library reads no environment variables).
  * Every option defaults to 0 = automatic; a value outside an option's range is PM_E_INVALID. */
@@ -95,7 +96,17 @@ enum {
     PM_OPT_KNN_XCD_TILE   = 8,  /* coarse kernels, workgroup order: 1 = launch order, 2 = one 2-D grid tile per XCD     */
     PM_OPT_KNN_GENERAL_F16 = 9, /* automatic L2 route on general floats: 1 = f32-input matrix pass (enqueued next to the
                                    f16 one), 2 = f16-rounded scaled copies, wider refinement window (default)   */
-    PM_OPT_COUNT_         = 10
+    PM_OPT_KNN_SEEDED     = 10, /* f16 hint route, row term -||t||^2/2: 1 = a k-chunk of its own (9 chunks, default: faster), 2 =
+                                   starts the accumulators from a per-tile LDS array (8 chunks).  1 also sends PM_KNN_HINT_U8
+                                   to the f16 pass (the u8 route exists in the seeded form only)                    */
+    PM_OPT_KNN_U8_GROUP   = 11, /* u8 route: rows per coarse candidate group, 1 = 4, 2 = 8 (default), 3 = 16                 */
+    PM_OPT_KNN_RING       = 12, /* u8 coarse kernel, train tiles: 1 = two LDS buffers (default), 2 = ring of eight with counted
+                                   waits and a workgroup barrier per tile, 3 = the ring with split-phase LDS counters
+                                   (2, 3: 8-row groups only; measured, not faster: DESIGN.md 2.1)                    */
+    PM_OPT_KNN_U8_REFINE  = 13, /* u8 route refinement: 1 = canonical f32 kernel (4-row groups only), 2 = integer
+                                   re-evaluation on the byte copies, one lane per row (default)                     */
+    PM_OPT_KNN_RING_PROLOGUE = 14, /* u8 ring kernel: train tiles requested before the sweep starts, 2 .. 8 (default 2)    */
+    PM_OPT_COUNT_         = 15
 };
 int  pm_ctx_set_option(pm_ctx* ctx, int option, int value);
 int  pm_ctx_get_option(pm_ctx* ctx, int option, int* value);
@@ -125,6 +136,9 @@ int  pm_version(void);                 /* major*100 + minor */
                                 /* (OpenCV SIFT: 0..255): only the exact f16-MFMA coarse route is   */
                                 /* launched.  The claim is verified on the device; a wrong hint     */
                                 /* costs time (exact re-scan), never correctness.                   */
+#define PM_KNN_HINT_U8      8   /* caller states the descriptors are integers in [0, 255] (OpenCV SIFT):  */
+                                /* ranked on the i8 matrix cores (x - 128, 4 k-chunks at D = 128, twice   */
+                                /* the f16 rate).  Verified on the device like PM_KNN_HINT_INTEGER.        */
 int pm_bf_knn_l2_f32(pm_ctx* ctx, const float* q, int nq, const float* t, int nt,
                      int dim, int k, int flags, pm_match* out);
 int pm_bf_knn_l2_f32_dev(pm_ctx* ctx, const float* d_q, int nq, const float* d_t, int nt,

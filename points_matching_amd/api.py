@@ -18,6 +18,7 @@ PM_MAX_K = 16
 PM_KNN_FORCE_EXACT = 1
 PM_KNN_FORCE_F32 = 2
 PM_KNN_HINT_INTEGER = 4
+PM_KNN_HINT_U8 = 8
 PM_ERR_SAMPSON = 0
 PM_ERR_SYM_EPIPOLAR = 1
 PM_OK, PM_E_INVALID, PM_E_TOO_FEW, PM_E_NO_MODEL, PM_E_HIP, PM_E_NOMEM, PM_E_UNSUPPORTED = \
@@ -68,6 +69,11 @@ PM_OPT_KNN_STAGING = 6
 PM_OPT_KNN_WG_PER_CU = 7
 PM_OPT_KNN_XCD_TILE = 8
 PM_OPT_KNN_GENERAL_F16 = 9
+PM_OPT_KNN_SEEDED = 10
+PM_OPT_KNN_U8_GROUP = 11
+PM_OPT_KNN_RING = 12
+PM_OPT_KNN_U8_REFINE = 13
+PM_OPT_KNN_RING_PROLOGUE = 14
 
 
 _lib = None

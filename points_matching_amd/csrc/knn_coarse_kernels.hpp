@@ -23,6 +23,7 @@ struct Abl {
     static constexpr bool no_stage = NO_STAGE;        // do not stage the next tile
     static constexpr bool no_barrier = NO_BARRIER;    // no workgroup barrier per tile
     static constexpr bool no_ldsread = NO_LDSREAD;    // A fragments read once, not per chunk
+    static __device__ __forceinline__ void stamp(int) {}   // in-kernel clock stamp i (diagnostic builds: tools/ablation/knn_coarse_stamps.hip)
 };
 typedef Abl<false, false, false, false> AblNone;
 
@@ -345,6 +346,7 @@ struct RouteF16 {
     static constexpr int LDS_ROW16 = H_LDS_ROW16;     // ... per LDS row (one pad slot)
     static constexpr int GPB = 4;                     // row groups per 32-row block and lane: groups of 4 rows
     static constexpr bool MERGE = true;               // one list per (query, split): float ties are rare
+    static constexpr bool SEEDED = false;             // the seed rides its own k-chunk
     typedef f16x8 frag;
     typedef f32x16 acc;
     typedef f32x4 list;
@@ -372,6 +374,7 @@ struct RouteI8 {
     static constexpr int GPB = 2;                     // groups of 8 rows: the popcount refinement is cheap
     static constexpr bool MERGE = false;              // integer distances tie all the time: a 4-deep merged list would
                                                       // overflow (and force split re-scans) for most queries
+    static constexpr bool SEEDED = false;             // Hamming: nothing to seed (dot = bits - 2*hamming)
     typedef i32x4 frag;
     typedef i32x16 acc;
     typedef i32x4 list;
@@ -406,6 +409,73 @@ struct RouteI8 {
         for (int i = 0; i < 4; ++i) cl[i] = cl[i] == I8_EMPTY ? I8_EMPTY : (cl[i] | h);
     }
 };
+
+// Seeded routes (knn_shared.hpp): the accumulators START from the per-row term, read from a per-tile seed array in LDS.
+//   RouteF16S  RouteF16 without the seed chunk: 256-byte rows = 8 k-chunks, every MFMA is algorithmic work;
+//   RouteU8    u8-valued descriptors centred to x - 128: v_mfma_i32_32x32x32_i8 on 128-byte rows = 4 k-chunks, exact
+//              integers, candidate = (w << U8_SHIFT) | id (no mantissa truncation, no error term but the seed's half unit).
+struct RouteF16S : RouteF16 {
+    static constexpr int NCH = F16S_NCH;
+    static constexpr int ROW16 = F16S_ROW16;
+    static constexpr int LDS_ROW16 = F16S_LDS_ROW16;
+    static constexpr bool SEEDED = true;
+};
+
+// GPB_ row groups per 32-row block and lane half: 4 = groups of 4 consecutive rows (the f16 route's geometry), 2 = groups
+// of 8 rows (two runs of 4, as on the Hamming route), 1 = the lane's 16 rows of the block.  Larger groups = fewer
+// selection instructions per descriptor pair (28 / 18 / 13 per block and wave) and more rows per candidate for the
+// integer refinement (knn_l2_refine8), which evaluates one row per lane.
+template <int GPB_>
+struct RouteU8T {
+    static constexpr int NCH = U8_NCH;
+    static constexpr int ROW16 = U8_ROW16;
+    static constexpr int LDS_ROW16 = U8_LDS_ROW16;
+    static constexpr int GPB = GPB_;
+    static constexpr int GROUP = 16 / GPB_;           // accumulator registers (rows) per group
+    static constexpr bool MERGE = true;               // squared distances of SIFT rows rarely tie
+    static constexpr bool SEEDED = true;
+    typedef i32x4 frag;
+    typedef i32x16 acc;
+    typedef i32x4 list;
+    static __device__ __forceinline__ acc zero() { return acc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; }
+    static __device__ __forceinline__ acc mfma(frag a, frag b, acc c)
+    {
+        return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ list empty() { return list{I8_EMPTY, I8_EMPTY, I8_EMPTY, I8_EMPTY}; }
+    static __device__ __forceinline__ int max3(int a, int b, int c) { return max(max(a, b), c); }     // v_max3_i32
+    static __device__ __forceinline__ void select(const acc& a, unsigned par, unsigned gid, list& cl, int g)
+    {
+        int m;
+        if constexpr (GROUP == 4) {
+            m = max(max3(a[4 * g], a[4 * g + 1], a[4 * g + 2]), a[4 * g + 3]);
+        } else if constexpr (GROUP == 8) {
+            const int m0 = max3(a[8 * g], a[8 * g + 1], a[8 * g + 2]);
+            const int m1 = max3(m0, a[8 * g + 3], a[8 * g + 4]);
+            m = max(max3(m1, a[8 * g + 5], a[8 * g + 6]), a[8 * g + 7]);
+        } else {
+            const int m0 = max3(a[0], a[1], a[2]), m1 = max3(a[3], a[4], a[5]), m2 = max3(a[6], a[7], a[8]);
+            const int m3 = max3(a[9], a[10], a[11]), m4 = max3(a[12], a[13], a[14]);
+            m = max(max3(m0, m1, m2), max3(m3, m4, a[15]));
+        }
+        (void)par;
+        RouteI8::insert(cl, static_cast<int>((static_cast<unsigned>(m) << U8_SHIFT) | gid));   // v_lshl_or_b32
+    }
+    static __device__ __forceinline__ void put(list& cl, int x) { RouteI8::insert(cl, x); }
+    static __device__ __forceinline__ void merge(list& cl, int h)
+    {
+        list own, other;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            own[i] = cl[i] == I8_EMPTY ? I8_EMPTY : (cl[i] | h);
+            other[i] = __shfl_xor(own[i], 32, 64);
+        }
+        cl = own;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) RouteI8::insert(cl, other[i]);
+    }
+};
+typedef RouteU8T<4> RouteU8;
 
 // a tile = 128 rows x R::ROW16 16-byte units, staged through registers by THREADS threads
 template <typename R, int THREADS>
@@ -481,12 +551,18 @@ struct HTileDma {
 // one 32-row block of the tile: 9 k-chunks x NQB query blocks of MFMAs, selecting the previous
 // block's accumulators p[] (group-id base pbase) in between, from chunk 1 on (see knn_tile_compute).
 // tb: this lane's row in the LDS tile, in 16-byte units (chunk c = tb[2*c])
+// sb (seeded routes): this lane's 64 bytes of the block's seeds in the LDS seed array (16-byte units): its 16 C-in
+// registers, read once per block and shared by the NQB query blocks
+struct Seed64 { uint4 v[4]; };
 template <typename R, int NQB, bool EPI, typename ABL>
-__device__ __forceinline__ void h_block(const uint4* __restrict__ tb, const typename R::frag (&qf)[NQB][R::NCH],
+__device__ __forceinline__ void h_block(const uint4* __restrict__ tb, const uint4* __restrict__ sb,
+                                        const typename R::frag (&qf)[NQB][R::NCH],
                                         typename R::acc (&a)[NQB], const typename R::acc (&p)[NQB], unsigned pbase,
                                         unsigned par, typename R::list (&cl)[NQB])
 {
     typedef typename R::frag frag;
+    typename R::acc seed = R::zero();
+    if constexpr (R::SEEDED) seed = __builtin_bit_cast(typename R::acc, Seed64{{sb[0], sb[1], sb[2], sb[3]}});
     // A fragments run three chunks ahead of their use: one chunk is only 32*NQB pipe cycles, less
     // than an LDS round trip
     frag ring[3];
@@ -499,7 +575,7 @@ __device__ __forceinline__ void h_block(const uint4* __restrict__ tb, const type
             if (c + 3 < R::NCH) ring[c % 3] = *reinterpret_cast<const frag*>(tb + 2 * (c + 3));
         }
 #pragma unroll
-        for (int qb = 0; qb < NQB; ++qb) a[qb] = R::mfma(x, qf[qb][c], c == 0 ? R::zero() : a[qb]);
+        for (int qb = 0; qb < NQB; ++qb) a[qb] = R::mfma(x, qf[qb][c], c == 0 ? seed : a[qb]);
         if constexpr (ABL::no_epi) {
             if (EPI && c == 1) {                  // timing-only build: the accumulators stay live, nothing is selected
 #pragma unroll
@@ -522,6 +598,72 @@ __device__ __forceinline__ void h_block(const uint4* __restrict__ tb, const type
     }
 }
 
+// One 128-row tile = 4 blocks as ONE stream of 4 * NCH (block, chunk) steps (ring kernel).  h_block primes its
+// A-fragment ring and reads its 16 seed registers at every block start: with NCH = 4 a block is only 128 matrix-pipe
+// cycles per wave, and the eight waves of a workgroup reach the block boundary together, so each boundary exposed an
+// LDS round trip behind a burst of 56 reads (stamps: 2100 cycles per tile against 1024 of MFMA).  Here the fragment
+// of step s + 3 is requested at step s ACROSS block boundaries and the seeds of block b + 1 are requested right after
+// block b's first MFMA has consumed block b's; only the tile boundary (a barrier: the next tile may not have landed)
+// starts cold.  Selection of the previous block's accumulators as in h_block.
+//   A, B  accumulator sets: blocks 0, 2 -> A, blocks 1, 3 -> B;  FIRST: no previous tile (block 0 selects nothing)
+template <typename R, int NQB, bool FIRST, typename ABL>
+__device__ __forceinline__ void h_tile(const uint4* __restrict__ tb, const uint4* __restrict__ sb,
+                                       const typename R::frag (&qf)[NQB][R::NCH], typename R::acc (&A)[NQB],
+                                       typename R::acc (&B)[NQB], unsigned lb, unsigned par, typename R::list (&cl)[NQB])
+{
+    typedef typename R::frag frag;
+    typedef typename R::acc acc;
+    constexpr int NCH = R::NCH, STEPS = 4 * NCH, PF = 3;
+    constexpr unsigned G = R::GPB;
+    auto a_ptr = [&](int step) { return reinterpret_cast<const frag*>(tb + (step / NCH) * 32 * R::LDS_ROW16 + 2 * (step % NCH)); };
+    auto seed_of = [&](int blk) {
+        if constexpr (R::SEEDED) {
+            const uint4* p = sb + 8 * blk;
+            return __builtin_bit_cast(acc, Seed64{{p[0], p[1], p[2], p[3]}});
+        } else {
+            return R::zero();
+        }
+    };
+    frag ring[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) ring[i] = *a_ptr(i);
+    acc seed = seed_of(0);
+#pragma unroll
+    for (int s_ = 0; s_ < STEPS; ++s_) {
+        const int blk = s_ / NCH, c = s_ % NCH;
+        const frag x = ring[s_ % PF];
+        if constexpr (!ABL::no_ldsread) {
+            if (s_ + PF < STEPS) ring[s_ % PF] = *a_ptr(s_ + PF);
+        }
+        acc(&cur)[NQB] = (blk & 1) ? B : A;
+        const acc(&prev)[NQB] = (blk & 1) ? A : B;
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) cur[qb] = R::mfma(x, qf[qb][c], c == 0 ? seed : cur[qb]);
+        if (c == 0 && blk < 3) seed = seed_of(blk + 1);
+        const bool epi = !(FIRST && blk == 0);
+        if constexpr (ABL::no_epi) {
+            if (epi && c == 1) {
+#pragma unroll
+                for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(prev[qb][e]));
+            }
+        }
+        if (epi && c >= 1 && !ABL::no_epi) {
+            constexpr int NGB = R::GPB * NQB;
+            const unsigned pbase = lb + G * static_cast<unsigned>(blk) - G;       // the previous block's group ids
+#pragma unroll
+            for (int e = (c - 1) * NGB / (NCH - 1); e < c * NGB / (NCH - 1); ++e)
+                R::select(prev[e % NQB], par, (pbase + static_cast<unsigned>(e / NQB)) << 1, cl[e % NQB], e / NQB);
+            if (NQB == 2)
+                asm volatile("" : "+v"(cl[0][0]), "+v"(cl[0][1]), "+v"(cl[0][2]), "+v"(cl[0][3]), "+v"(cl[NQB - 1][0]),
+                             "+v"(cl[NQB - 1][1]), "+v"(cl[NQB - 1][2]), "+v"(cl[NQB - 1][3]));
+            else
+                asm volatile("" : "+v"(cl[0][0]), "+v"(cl[0][1]), "+v"(cl[0][2]), "+v"(cl[0][3]));
+        }
+    }
+}
+
 // NQB query blocks (of 32) per wave: 2 -> 4 waves per workgroup, 2 waves per SIMD (each A fragment
 // feeds two MFMAs); 1 -> 8 waves per workgroup, 4 waves per SIMD at <= 128 VGPRs (more waves to
 // cover LDS / barrier / MFMA-dependency latency).  Either way a workgroup owns H_QB = 256 queries.
@@ -533,9 +675,9 @@ __device__ __forceinline__ void h_block(const uint4* __restrict__ tb, const type
 // mode bit 0: 0 = run always (hint / i8), 1 = run only if prep16 found the data eligible (auto); bit 1: XCD-tiled grid
 template <typename R, int NQB, bool DMA, int GR, typename ABL>
 __global__ __launch_bounds__(H_QB / (32 * NQB) * 64 * GR, (NQB == 2 ? 2 : 4)) void knn_mfma_rows288(
-    const uint4* __restrict__ Qh, const uint4* __restrict__ Th, int nq, int nt, int tiles_per_split, unsigned par,
-    typename R::list* __restrict__ cand_val, int slots, const unsigned long long* __restrict__ stats, unsigned epoch,
-    int mode)
+    const uint4* __restrict__ Qh, const uint4* __restrict__ Th, const uint4* __restrict__ seeds_g, int nq, int nt,
+    int tiles_per_split, unsigned par, typename R::list* __restrict__ cand_val, int slots,
+    const unsigned long long* __restrict__ stats, unsigned epoch, int mode)
 {
     typedef typename R::frag frag;
     typedef typename R::acc acc;
@@ -548,7 +690,10 @@ __global__ __launch_bounds__(H_QB / (32 * NQB) * 64 * GR, (NQB == 2 ? 2 : 4)) vo
         if (static_cast<unsigned>(s1 >> 32) == epoch && (s1 & 2ull) && static_cast<unsigned>(s3 >> 32) == epoch)
             return;                    // not integer-valued AND the rounded-copy route withdrew: the f32 kernel takes over
     }
-    extern __shared__ __attribute__((aligned(16))) uint4 hsm[];                   // [2][H_TT][R::LDS_ROW16]
+    extern __shared__ __attribute__((aligned(16))) uint4 hsm[];                   // [2][H_TT][R::LDS_ROW16] (+ [2][64] seeds)
+    static_assert(!R::SEEDED || DMA, "the seeded routes stage by LDS-DMA only");
+    constexpr int TILE_SLOTS = H_TT * R::LDS_ROW16;
+    uint4* const ssm = hsm + 2 * TILE_SLOTS;                                      // seeded routes: [2][64] (1 KiB per DMA piece, 512 B used)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int gw = wave % WPG, grp = wave / WPG;           // wave inside its row group, row group
@@ -562,9 +707,18 @@ __global__ __launch_bounds__(H_QB / (32 * NQB) * 64 * GR, (NQB == 2 ? 2 : 4)) vo
     const int tile0 = wg.split * tiles_per_split;
     const __amdgpu_buffer_rsrc_t t_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint4*>(Th), 0, ntiles * (H_TT * R::ROW16 * 16), 0x00020000);
+    // seeds: one more 1-KiB piece per tile, issued by the last wave (the source array carries one tile of slack)
+    const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4*>(R::SEEDED ? seeds_g : Th), 0, (ntiles + 1) * SEED_TILE_BYTES, 0x00020000);
+    auto seed_issue = [&](int tile, int buf) {
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        if (R::SEEDED && wave == THREADS / 64 - 1)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (lptr_t)(ssm + 64 * buf), 16, lane * 16, tile * SEED_TILE_BYTES, 0, 0);
+    };
     if (DMA) {
         dma.init(lane, wave);
         dma.issue(t_rsrc, tile0 < ntiles ? tile0 : ntiles - 1, hsm, 0, wave);
+        seed_issue(tile0 < ntiles ? tile0 : ntiles - 1, 0);
     } else {
         st.load(Th, tile0 < ntiles ? tile0 : ntiles - 1, tid);      // unconditional (clamped): nt >= 1
     }
@@ -604,28 +758,32 @@ __global__ __launch_bounds__(H_QB / (32 * NQB) * 64 * GR, (NQB == 2 ? 2 : 4)) vo
             // the last tile is simply staged again: past the end nothing reads the other buffer
             if constexpr (!ABL::no_stage) {
                 // the other buffer was last read in tile tix - 1, and every wave has passed that tile's barrier
-                if (DMA) dma.issue(t_rsrc, tile0 + tix + 1 < ntiles ? tile0 + tix + 1 : tile0 + tix, hsm, buf ^ 1, wave);
-                else st.load(Th, tile0 + tix + 1 < ntiles ? tile0 + tix + 1 : tile0 + tix, tid);
+                if (DMA) {
+                    dma.issue(t_rsrc, tile0 + tix + 1 < ntiles ? tile0 + tix + 1 : tile0 + tix, hsm, buf ^ 1, wave);
+                    seed_issue(tile0 + tix + 1 < ntiles ? tile0 + tix + 1 : tile0 + tix, buf ^ 1);
+                } else st.load(Th, tile0 + tix + 1 < ntiles ? tile0 + tix + 1 : tile0 + tix, tid);
             }
+            const uint4* sb = ssm + 64 * buf + 4 * h;             // block b of the tile: sb + 8 * b
             if constexpr (GR == 1) {
-                if (tix == 0) h_block<R, NQB, false, ABL>(tb, qf, A, A, 0u, par, cl);
-                else h_block<R, NQB, true, ABL>(tb, qf, A, B, lb - G, par, cl);                     // B = block 3 of tile-1
-                h_block<R, NQB, true, ABL>(tb + 32 * R::LDS_ROW16, qf, B, A, lb, par, cl);
-                h_block<R, NQB, true, ABL>(tb + 64 * R::LDS_ROW16, qf, A, B, lb + G, par, cl);
+                if (tix == 0) h_block<R, NQB, false, ABL>(tb, sb, qf, A, A, 0u, par, cl);
+                else h_block<R, NQB, true, ABL>(tb, sb, qf, A, B, lb - G, par, cl);                 // B = block 3 of tile-1
+                h_block<R, NQB, true, ABL>(tb + 32 * R::LDS_ROW16, sb + 8, qf, B, A, lb, par, cl);
+                h_block<R, NQB, true, ABL>(tb + 64 * R::LDS_ROW16, sb + 16, qf, A, B, lb + G, par, cl);
                 if constexpr (!ABL::no_stage) {
                     if (!DMA) st.store(hsm, buf ^ 1, tid);
                 }
-                h_block<R, NQB, true, ABL>(tb + 96 * R::LDS_ROW16, qf, B, A, lb + 2u * G, par, cl);
+                h_block<R, NQB, true, ABL>(tb + 96 * R::LDS_ROW16, sb + 24, qf, B, A, lb + 2u * G, par, cl);
             } else {
                 // this group's blocks 2*grp and 2*grp + 1 of the tile (group ids lb + G*block + g, as above)
                 const uint4* tg = tb + grp * 64 * R::LDS_ROW16;
+                const uint4* sg = sb + 16 * grp;
                 const unsigned gb = lb + 2u * static_cast<unsigned>(grp) * G;
-                if (tix == 0) h_block<R, NQB, false, ABL>(tg, qf, A, A, 0u, par, cl);
-                else h_block<R, NQB, true, ABL>(tg, qf, A, B, gb - 3u * G, par, cl);                // B = block 2*grp+1 of tile-1
+                if (tix == 0) h_block<R, NQB, false, ABL>(tg, sg, qf, A, A, 0u, par, cl);
+                else h_block<R, NQB, true, ABL>(tg, sg, qf, A, B, gb - 3u * G, par, cl);            // B = block 2*grp+1 of tile-1
                 if constexpr (!ABL::no_stage) {
                     if (!DMA) st.store(hsm, buf ^ 1, tid);
                 }
-                h_block<R, NQB, true, ABL>(tg + 32 * R::LDS_ROW16, qf, B, A, gb, par, cl);
+                h_block<R, NQB, true, ABL>(tg + 32 * R::LDS_ROW16, sg + 8, qf, B, A, gb, par, cl);
             }
             tile_barrier<ABL>();
         }
@@ -668,6 +826,227 @@ __global__ __launch_bounds__(H_QB / (32 * NQB) * 64 * GR, (NQB == 2 ? 2 : 4)) vo
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Ring form of the row-streaming kernel (round 3).  With 4 k-chunks per block (u8 route) a 128-row tile is only
+// ~1000 matrix-pipe cycles per SIMD — less than one LDS-DMA round trip — so the double-buffered form above, which
+// requests tile t+1 when tile t starts and waits vmcnt(0) at tile t's barrier, exposes the memory latency once per
+// tile.  Here the tiles live in a ring of NBUF LDS buffers (u8: 8 x 19 KiB = the whole 1024-row split of config C3):
+//   prologue     query fragments, then tiles 0 .. NBUF-2 are requested back to back;
+//   tile t       s_waitcnt vmcnt(own pieces of the tiles after t still allowed in flight) ; s_barrier ;
+//                request tile t-1+NBUF into the buffer tile t-1 just left ; 4 blocks of MFMAs + selection.
+// One barrier per tile serves both hazards (every wave's pieces of tile t have landed; every wave is done with tile
+// t-1), the waits are COUNTED (vmcnt retires in order; a wave issues the same number of pieces for every tile), and no
+// fence is involved (a __syncthreads() would drain vmcnt to 0).  GR = 1 only.
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_imm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// wait until at most `ahead` tiles' worth of this wave's requests are in flight; a wave issues BASE or BASE + 1
+// vector-memory operations per tile (`plus`), ahead <= 6
+template <int BASE>
+__device__ __forceinline__ void wait_tiles(int ahead, bool plus)
+{
+    static_assert(7 * (BASE + 1) <= 63, "vmcnt is a 6-bit counter");
+#define PM_W(A_) case A_: if (plus) wait_vmcnt_imm<A_ * (BASE + 1)>(); else wait_vmcnt_imm<A_ * BASE>(); break;
+    switch (ahead) {
+        PM_W(1) PM_W(2) PM_W(3) PM_W(4) PM_W(5) PM_W(6) PM_W(7)
+        default: wait_vmcnt_imm<0>(); break;
+    }
+#undef PM_W
+}
+
+// 16-byte global load the compiler does not track: no s_waitcnt is generated for it, so it can stay in flight behind
+// later LDS-DMA requests (a tracked load issued before a loop of requests makes hipcc wait vmcnt(0) at its first use,
+// i.e. for every request of the loop).  The caller waits (wait_tiles) and then passes the registers through
+// pin_after_wait() before their first use.
+template <typename FRAG>
+__device__ __forceinline__ FRAG untracked_load16(const void* p)
+{
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p) : "memory");
+    return __builtin_bit_cast(FRAG, v);
+}
+template <typename FRAG>
+__device__ __forceinline__ void pin_after_wait(FRAG& f)
+{
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 t = __builtin_bit_cast(u32x4, f);
+    asm volatile("" : "+v"(t)::"memory");
+    f = __builtin_bit_cast(FRAG, t);
+}
+
+// WAVES waves of 32 * NQB queries each: 8 x 32 or 4 x 64 (256 queries per workgroup, as knn_mfma_rows288), or 16 x 32
+// (512 queries: four waves per SIMD cover each other's LDS and issue stalls; twice the splits, half the tiles each).
+// SPLIT: no workgroup barrier inside the sweep.  Stamps of the barrier form: 2100 cycles per tile with the barrier,
+// 1520 without it (8 waves; 3280 against 1710 with 16) — waves that meet every ~1000 matrix-pipe cycles spend a third of
+// their time waiting for the slowest of them.  The split-phase form keeps two monotonic counters per ring buffer in LDS:
+//   arrive[b]  += 1 by every wave once ITS pieces of the tile in buffer b have landed (counted vmcnt wait), done one
+//              tile AHEAD: a wave signals tile t + 1 before it starts computing tile t;
+//   done[b]    += 1 by every wave when it has finished the tile in buffer b (only read when a buffer is re-used).
+// A wave entering tile t polls arrive[t % NBUF] >= WAVES * (t / NBUF + 1) — normally true for a whole tile time
+// already — and a wave requesting tile j >= NBUF polls done[j % NBUF] >= WAVES * (j / NBUF).  Waves drift apart by up
+// to a tile (NBUF - 1 for the buffers) instead of meeting at every tile; LDS operations of a wave execute in order,
+// so the counter read orders the tile reads behind it.
+template <typename R, int NQB, int WAVES, int NBUF, bool SPLIT, typename ABL>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void knn_mfma_ring(
+    const uint4* __restrict__ Qh, const uint4* __restrict__ Th, const uint4* __restrict__ seeds_g, int nq, int nt,
+    int tiles_per_split, unsigned par, typename R::list* __restrict__ cand_val, int slots, int mode, int pro)
+{
+    typedef typename R::frag frag;
+    typedef typename R::acc acc;
+    typedef typename R::list list;
+    constexpr int THREADS = WAVES * 64;
+    constexpr int QB_WG = WAVES * 32 * NQB;                  // queries per workgroup
+    constexpr int TILE_SLOTS = H_TT * R::LDS_ROW16;
+    typedef HTileDma<R, THREADS> Dma;
+    static_assert(NBUF >= 3 && NBUF <= 8, "ring of three to eight buffers (wait_tiles covers up to 7 tiles in flight)");
+    extern __shared__ __attribute__((aligned(16))) uint4 hsm[];                   // [NBUF][H_TT][R::LDS_ROW16] + [NBUF][64] seeds
+    uint4* const ssm = hsm + NBUF * TILE_SLOTS;
+    int* const arrive = reinterpret_cast<int*>(ssm + NBUF * 64);                  // [NBUF] arrive + [NBUF] done (SPLIT)
+    int* const done = arrive + NBUF;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const WgTile wg = wg_tile((mode & 2) != 0);
+    const int qbase = wg.qb * QB_WG + wave * 32 * NQB;
+    ABL::stamp(0);
+    if constexpr (SPLIT) {                                    // counters start at zero; the only workgroup barrier of the kernel
+        if (tid < 2 * NBUF) arrive[tid] = 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    auto poll = [&](int* ctr, int target) {                  // wave-uniform spin on an LDS counter
+        for (;;) {
+            const int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (v >= target) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+    };
+    auto bump = [&](int* ctr) {
+        if (lane == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add_u32, no return
+    };
+
+    const int ntiles = (nt + H_TT - 1) / H_TT;
+    const int tile0 = wg.split * tiles_per_split;
+    int tile1 = tile0 + tiles_per_split;
+    if (tile1 > ntiles) tile1 = ntiles;
+    const int ntl = tile1 - tile0;
+
+    // query fragments first: they are the oldest vector-memory operations, so the first counted wait covers them
+    frag qf[NQB][R::NCH];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+        for (int c = 0; c < R::NCH; ++c)
+            qf[qb][c] = untracked_load16<frag>(Qh + static_cast<size_t>(qbase + 32 * qb + r) * R::ROW16 + 2 * c + h);
+
+    const __amdgpu_buffer_rsrc_t t_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4*>(Th), 0, ntiles * (H_TT * R::ROW16 * 16), 0x00020000);
+    const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4*>(R::SEEDED ? seeds_g : Th), 0, (ntiles + 1) * SEED_TILE_BYTES, 0x00020000);
+    Dma dma;
+    dma.init(lane, wave);
+    // vector-memory operations this wave issues per tile: its share of the NPIECES pieces (+ the seed piece on the last
+    // wave) = BASE or BASE + 1
+    constexpr int BASE = Dma::NPIECES / Dma::NW;
+    const int own = (Dma::NPIECES - wave + Dma::NW - 1) / Dma::NW + ((R::SEEDED && wave == Dma::NW - 1) ? 1 : 0);
+    const bool plus = __builtin_amdgcn_readfirstlane(own) != BASE;
+    static_assert(Dma::NPIECES >= Dma::NW, "every wave issues at least one piece");
+    auto request = [&](int t) {                              // tile t of the split -> ring buffer t % NBUF
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        const int buf = t % NBUF;
+        dma.issue(t_rsrc, tile0 + t, hsm, buf, wave);        // (buffer stride = TILE_SLOTS: HTileDma::SLOTS)
+        if (R::SEEDED && wave == Dma::NW - 1)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (lptr_t)(ssm + 64 * buf), 16, lane * 16, (tile0 + t) * SEED_TILE_BYTES, 0, 0);
+    };
+    // tile j may be requested once tile j - NBUF is done.  `next` = first tile not yet requested.  The prologue asks
+    // for `pro` tiles only (a request costs the issuing wave ~100-200 cycles while the memory pipe is busy: asking for the
+    // whole ring up front would keep every wave from its first MFMA for ~4000 cycles); the sweep then asks for up to
+    // two more per tile until the ring is full.
+    int next = 0;
+    auto pump = [&](int done_below, int most) {             // tiles < done_below are finished (by THIS wave when SPLIT)
+        for (int n = 0; n < most && next < ntl && next < done_below + NBUF; ++n) {
+            if constexpr (SPLIT) {
+                if (next >= NBUF) poll(&done[next % NBUF], WAVES * (next / NBUF));    // every wave has left the buffer's last tile
+            }
+            request(next);
+            ++next;
+        }
+    };
+    pump(0, pro);
+    if constexpr (SPLIT) {
+        if (ntl > 0) {                                       // arrive for tile 0 (later tiles: one tile ahead, inside the sweep)
+            wait_tiles<BASE>(next - 1, plus);
+            bump(&arrive[0]);
+        }
+    }
+    ABL::stamp(1);
+
+    list cl[NQB];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) cl[qb] = R::empty();
+
+    if (ntl > 0) {
+        acc A[NQB], B[NQB];
+        constexpr unsigned G = R::GPB;
+#pragma unroll 1
+        for (int tix = 0; tix < ntl; ++tix) {
+            if constexpr (SPLIT) {
+                // every wave's pieces of tile tix have landed?  (this wave arrived for it one tile ago)
+                if constexpr (!ABL::no_barrier) poll(&arrive[tix % NBUF], WAVES * (tix / NBUF + 1));
+                if constexpr (!ABL::no_stage) pump(tix, 2);
+                if (tix + 1 < ntl) {                         // arrive for tile tix + 1 (requested: the pump keeps two tiles ahead)
+                    wait_tiles<BASE>(next - 2 - tix, plus);
+                    bump(&arrive[(tix + 1) % NBUF]);
+                }
+            } else {
+                // tiles after tix that may stay in flight: everything requested so far beyond tix
+                wait_tiles<BASE>(next - 1 - tix, plus);     // (also covers the query fragments: they are older than tile 0)
+                if constexpr (!ABL::no_barrier) __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+                for (int c = 0; c < R::NCH; ++c) pin_after_wait(qf[qb][c]);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!SPLIT && !ABL::no_stage) pump(tix, 2);
+            if (tix < 14) ABL::stamp(2 + tix);
+            const int buf = tix % NBUF;
+            const uint4* tb = hsm + (buf * H_TT + r) * R::LDS_ROW16 + h;
+            const uint4* sb = ssm + 64 * buf + 4 * h;
+            const unsigned lb = static_cast<unsigned>(tix) * (4u * G);
+            if (tix == 0) h_tile<R, NQB, true, ABL>(tb, sb, qf, A, B, lb, par, cl);
+            else h_tile<R, NQB, false, ABL>(tb, sb, qf, A, B, lb, par, cl);
+            if constexpr (SPLIT) {
+                if (tix + NBUF < ntl) bump(&done[tix % NBUF]);                   // (only a re-used buffer is ever polled)
+            }
+        }
+        const unsigned lb = static_cast<unsigned>(ntl - 1) * (4u * G) + 3u * G;
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+            for (int g = 0; g < R::GPB; ++g) R::select(B[qb], par, (lb + static_cast<unsigned>(g)) << 1, cl[qb], g);
+    }
+    ABL::stamp(16);
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+        const int q = qbase + 32 * qb + r;
+        R::merge(cl[qb], h);
+        if (R::MERGE) {
+            if (q < nq && h == 0) cand_val[(static_cast<size_t>(q) * slots + wg.split * KNN_C) / KNN_C] = cl[qb];
+        } else {
+            if (q < nq) cand_val[(static_cast<size_t>(q) * slots + (wg.split * 2 + h) * KNN_C) / KNN_C] = cl[qb];
+        }
+    }
+    ABL::stamp(17);
+}
+
+// the DMA form addresses a train copy through a buffer descriptor with 32-bit byte offsets
+template <typename R>
+inline bool rows288_dma_ok(int nt) { return (static_cast<long long>(nt) + H_TT) * (R::ROW16 * 16) < 0x7FFFFFFFLL; }
 
 // PM_OPT_KNN_XCD_TILE: 1 = launch order, 2 = tiled (the default; wg_tile falls back when the grid shape does not divide)
 inline bool xcd_tiled(const pm_ctx* ctx) { return ctx->opts[PM_OPT_KNN_XCD_TILE] != 1; }
@@ -714,11 +1093,11 @@ int coarse_f32_dispatch(pm_ctx* ctx, const float* dq, int nq, const float* dt, i
 }
 
 template <typename R, typename ABL>
-int launch_rows288(pm_ctx* ctx, const char* name, const void* Qh, const void* Th, int nq, int nq_pad, int nt, int splits,
-                   int tiles_per_split, unsigned par, void* cval, int slots, const unsigned long long* stats,
+int launch_rows288(pm_ctx* ctx, const char* name, const void* Qh, const void* Th, const void* seeds, int nq, int nq_pad, int nt,
+                   int splits, int tiles_per_split, unsigned par, void* cval, int slots, const unsigned long long* stats,
                    unsigned epoch, int mode)
 {
-    const size_t lds = sizeof(uint4) * 2 * H_TT * R::LDS_ROW16;
+    const size_t lds = sizeof(uint4) * (2 * H_TT * R::LDS_ROW16 + (R::SEEDED ? 2 * 64 : 0));
     // few tiles per workgroup: the 8-wave form covers latency better; long sweeps: the 4-wave form halves LDS reads
     const int nqb_opt = ctx->opts[PM_OPT_KNN_F16_WAVES];
     const int nqb = nqb_opt ? nqb_opt : (tiles_per_split <= 8 ? 1 : 2);          // 3: two row groups of 4 waves x 64 queries
@@ -728,37 +1107,113 @@ int launch_rows288(pm_ctx* ctx, const char* name, const void* Qh, const void* Th
 #define PM_ATTR(NQB_, DMA_, GR_)                                                                                  \
     PM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_mfma_rows288<R, NQB_, DMA_, GR_, ABL>),        \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)))
-        PM_ATTR(1, false, 1); PM_ATTR(2, false, 1); PM_ATTR(1, true, 1); PM_ATTR(2, true, 1);
-        if constexpr (R::MERGE) { PM_ATTR(2, false, 2); PM_ATTR(2, true, 2); }
+        PM_ATTR(1, true, 1); PM_ATTR(2, true, 1);
+        if constexpr (!R::SEEDED) { PM_ATTR(1, false, 1); PM_ATTR(2, false, 1); }
+        if constexpr (R::MERGE) {
+            PM_ATTR(2, true, 2);
+            if constexpr (!R::SEEDED) PM_ATTR(2, false, 2);
+        }
 #undef PM_ATTR
         attr_done = true;
     }
     pm::ScopedKernelTime t(ctx, name);
     const uint4* q4 = static_cast<const uint4*>(Qh);
     const uint4* t4 = static_cast<const uint4*>(Th);
+    const uint4* s4 = static_cast<const uint4*>(seeds);
     typename R::list* out = static_cast<typename R::list*>(cval);
     // train tiles by LDS-DMA unless pinned to register staging (measured: C3 f16 21.3 -> 19.3 us, 32k x 32k f16 233 -> 210 us,
     // C4 i8 211 -> 198 us: the ds_write_b128 pass and 16 staging VGPRs disappear)
-    // (the DMA form addresses the train copy through a buffer descriptor with 32-bit byte offsets: below 2 GiB only)
-    const bool dma = ctx->opts[PM_OPT_KNN_STAGING] != 1 &&
-                     (static_cast<long long>(nt) + H_TT) * (R::ROW16 * 16) < 0x7FFFFFFFLL;
+    // (the DMA form addresses the train copy through a buffer descriptor with 32-bit byte offsets: below 2 GiB only;
+    // the seeded routes exist in the DMA form only: their callers check rows288_dma_ok first)
+    const bool dma = R::SEEDED || (ctx->opts[PM_OPT_KNN_STAGING] != 1 && rows288_dma_ok<R>(nt));
+    PM_REQUIRE(!R::SEEDED || rows288_dma_ok<R>(nt), PM_E_UNSUPPORTED, "train set too large for the seeded coarse routes");
 #define PM_GO(NQB_, DMA_, GR_, THREADS_)                                                                           \
     hipLaunchKernelGGL((knn_mfma_rows288<R, NQB_, DMA_, GR_, ABL>), dim3(nq_pad / H_QB, splits), dim3(THREADS_), lds,  \
-                       ctx->stream, q4, t4, nq, nt, tiles_per_split, par, out, slots, stats, epoch, mode)
+                       ctx->stream, q4, t4, s4, nq, nt, tiles_per_split, par, out, slots, stats, epoch, mode)
+#define PM_GO2(NQB_, GR_, THREADS_)                                                                                \
+    do {                                                                                                           \
+        if constexpr (R::SEEDED) { PM_GO(NQB_, true, GR_, THREADS_); }                                             \
+        else { if (dma) PM_GO(NQB_, true, GR_, THREADS_); else PM_GO(NQB_, false, GR_, THREADS_); }                \
+    } while (0)
     mode = (mode ? 1 : 0) | (xcd_tiled(ctx) ? 2 : 0);     // see wg_tile
     bool grouped = false;
     if constexpr (R::MERGE) {
         if (nqb == 3) {
             grouped = true;
-            if (dma) PM_GO(2, true, 2, 512); else PM_GO(2, false, 2, 512);
+            PM_GO2(2, 2, 512);
         }
     }
     if (grouped) { }
-    else if (nqb == 2) { if (dma) PM_GO(2, true, 1, 256); else PM_GO(2, false, 1, 256); }
-    else { if (dma) PM_GO(1, true, 1, 512); else PM_GO(1, false, 1, 512); }
+    else if (nqb == 2) PM_GO2(2, 1, 256);
+    else PM_GO2(1, 1, 512);
+#undef PM_GO2
 #undef PM_GO
     PM_HIP_CHECK(hipGetLastError());
     return PM_OK;
+}
+
+// ring form (knn_mfma_ring): NBUF buffers of one tile (+ 1 KiB of seeds) each.  qb_wg: queries per workgroup the caller
+// sized nq_pad and the splits for (ring_qb_wg below).
+inline int ring_qb_wg(const pm_ctx* ctx) { return ctx->opts[PM_OPT_KNN_F16_WAVES] == 3 ? 512 : 256; }
+template <typename R, int NBUF, typename ABL>
+int launch_ring(pm_ctx* ctx, const char* name, const void* Qh, const void* Th, const void* seeds, int nq, int nq_pad, int nt,
+                int splits, int tiles_per_split, unsigned par, void* cval, int slots)
+{
+    const size_t lds = static_cast<size_t>(NBUF) * (sizeof(uint4) * H_TT * R::LDS_ROW16 + 1024) + 64;      // + the counters
+    static_assert(static_cast<size_t>(NBUF) * (sizeof(uint4) * H_TT * R::LDS_ROW16 + 1024) + 64 <= 160 * 1024, "ring exceeds the CU's LDS");
+    const bool split = ctx->opts[PM_OPT_KNN_RING] == 3;      // 2: workgroup barrier per tile; 3: split-phase LDS counters
+    PM_REQUIRE(rows288_dma_ok<R>(nt), PM_E_UNSUPPORTED, "train set too large for the LDS-DMA coarse routes");
+    const int form = ctx->opts[PM_OPT_KNN_F16_WAVES];       // 0 / 1: 8 waves x 32 queries, 2: 4 x 64, 3: 16 x 32
+    const int qb_wg = ring_qb_wg(ctx);
+    PM_REQUIRE(nq_pad % qb_wg == 0, PM_E_INVALID, "query padding does not match the workgroup size");
+    static bool attr_done_dev[PM_MAX_DEVICES] = {};
+    bool& attr_done = attr_done_dev[ctx->device];
+    if (!attr_done) {
+#define PM_ATTR(NQB_, WAVES_)                                                                                        \
+    PM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_mfma_ring<R, NQB_, WAVES_, NBUF, false, ABL>),    \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                \
+    PM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_mfma_ring<R, NQB_, WAVES_, NBUF, true, ABL>),     \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)))
+        PM_ATTR(1, 8); PM_ATTR(2, 4); PM_ATTR(1, 16);
+#undef PM_ATTR
+        attr_done = true;
+    }
+    pm::ScopedKernelTime t(ctx, name);
+    const uint4* q4 = static_cast<const uint4*>(Qh);
+    const uint4* t4 = static_cast<const uint4*>(Th);
+    const uint4* s4 = static_cast<const uint4*>(seeds);
+    typename R::list* out = static_cast<typename R::list*>(cval);
+    const int mode = xcd_tiled(ctx) ? 2 : 0;
+    int pro = ctx->opts[PM_OPT_KNN_RING_PROLOGUE] ? ctx->opts[PM_OPT_KNN_RING_PROLOGUE] : 2;   // tiles requested up front
+    if (pro < 2) pro = 2;                                    // (the split-phase form signals one tile ahead)
+#define PM_GO1(NQB_, WAVES_, SPLIT_)                                                                                \
+    hipLaunchKernelGGL((knn_mfma_ring<R, NQB_, WAVES_, NBUF, SPLIT_, ABL>), dim3(nq_pad / qb_wg, splits), dim3(WAVES_ * 64), lds, \
+                       ctx->stream, q4, t4, s4, nq, nt, tiles_per_split, par, out, slots, mode, pro)
+#define PM_GO(NQB_, WAVES_) do { if (split) PM_GO1(NQB_, WAVES_, true); else PM_GO1(NQB_, WAVES_, false); } while (0)
+    if (form == 3) PM_GO(1, 16);
+    else if (form == 2) PM_GO(2, 4);
+    else PM_GO(1, 8);
+#undef PM_GO
+#undef PM_GO1
+    PM_HIP_CHECK(hipGetLastError());
+    return PM_OK;
+}
+
+// u8 route: group size (rows per candidate group) x staging form
+template <typename ABL>
+int coarse_u8_dispatch(pm_ctx* ctx, const void* Q8, const void* T8, const int* seeds, int nq, int nq_pad, int nt, int splits,
+                       int tiles_per_split, int* cval, int slots, int group_rows, bool ring)
+{
+    // the ring form (measured, not the default: see knn_mfma_ring) exists for the default group size only
+    if (ring && group_rows == 8)
+        return launch_ring<RouteU8T<2>, 8, ABL>(ctx, "knn_l2_mfma_u8", Q8, T8, seeds, nq, nq_pad, nt, splits, tiles_per_split, 0u, cval, slots);
+#define PM_U8(GPB_)                                                                                                        \
+    launch_rows288<RouteU8T<GPB_>, ABL>(ctx, "knn_l2_mfma_u8", Q8, T8, seeds, nq, nq_pad, nt, splits, tiles_per_split, 0u, cval,   \
+                                        slots, nullptr, 0u, 0)
+    if (group_rows == 16) return PM_U8(1);
+    if (group_rows == 8) return PM_U8(2);
+    return PM_U8(4);
+#undef PM_U8
 }
 
 }  // namespace

@@ -165,12 +165,17 @@ __global__ __launch_bounds__(256) void knn_l2_prep(const float* __restrict__ Q, 
 // (The coarse kernel itself lives in knn_coarse.hip.  One row group per workgroup instead of the
 // 4-iteration loop below was measured slower: 11.7 vs 8.3 us at C3.)
 // ---------------------------------------------------------------------------------------------
+// SEEDED (round 3, hint route): rows of 128 halfs with no seed chunk; -||t||^2/2 goes to `seeds` (seed order,
+// knn_shared.hpp) and starts the accumulators of the coarse kernel instead (RouteF16S).
+template <bool SEEDED>
 __global__ __launch_bounds__(256) void knn_l2_prep16(const float* __restrict__ Q, int nq, int nq_pad,
                                                      const float* __restrict__ T, int nt, int nt_pad, int dim,
                                                      float* __restrict__ qnorm, float* __restrict__ tnorm,
                                                      _Float16* __restrict__ Qh, _Float16* __restrict__ Th,
+                                                     float* __restrict__ seeds,
                                                      unsigned long long* __restrict__ stats, unsigned epoch)
 {
+    constexpr int ROWH = SEEDED ? H_DP : H_ROW;
     __shared__ unsigned wmax[4];
     __shared__ unsigned wbad[4];
     const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
@@ -219,12 +224,17 @@ __global__ __launch_bounds__(256) void knn_l2_prep16(const float* __restrict__ Q
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
         if (!okrow) bad |= 2u;
-        *reinterpret_cast<f16x8*>(xh + static_cast<size_t>(row) * H_ROW + c0) = hv;
+        *reinterpret_cast<f16x8*>(xh + static_cast<size_t>(row) * ROWH + c0) = hv;
         if (sub == 0) {
             if (live) {
                 norm[row] = s;
                 if (!(s < KNN_INF)) bad |= 3u;
                 else if (is_t) mx = max(mx, f32_bits(s));
+            }
+            if constexpr (SEEDED) {
+                // exact when eligible (||t||^2 an integer below 2^24); rows padding the last tile sit below every real row
+                if (is_t) seeds[seed_pos(row)] = live ? -0.5f * s : -1.0e30f;
+                continue;
             }
             f16x8 e0 = {0, 0, 0, 0, 0, 0, 0, 0};
             const f16x8 e1 = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -262,6 +272,85 @@ __global__ __launch_bounds__(256) void knn_l2_prep16(const float* __restrict__ Q
         // f16-eligible) or 3 (both): 3 >= 2 >= 1 keeps "not eligible" visible once any block saw it,
         // and a non-finite input is never eligible.
         if (bad) atomicMax(&stats[1], tag | static_cast<unsigned long long>(bad == 1u ? 3u : bad));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// u8 route (round 3): u8-valued descriptors — what OpenCV's SIFT emits, 0..255 stored as float (BASELINE configs 2, 3,
+// 5) — are centred to x - 128 and ranked on v_mfma_i32_32x32x32_i8: 128-byte rows (4 k-chunks instead of the f16
+// route's 9), exact integer dot products, the per-row term -(||t - 128||^2 >> 1) starting the accumulators from the
+// per-tile seed array (knn_shared.hpp).  Coarse squared distance of (q, t): ||q'||^2 - 2w = d2 or d2 - 1.
+// knn_l2_prep8 writes the centred byte copies (padded to whole tiles, pad rows zero with the pad seed), ||q'||^2 and
+// the seeds, and VERIFIES the premise (integers in [0, 255]); a wrong hint raises bit 1 of stats[1] and the refinement
+// re-scans exactly, as on the f16 hint route.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void knn_l2_prep8(const float* __restrict__ Q, int nq, int nq_pad,
+                                                    const float* __restrict__ T, int nt, int nt_pad, int dim,
+                                                    float* __restrict__ qnorm, float* __restrict__ tnorm,
+                                                    uint2* __restrict__ Q8, uint2* __restrict__ T8,
+                                                    int* __restrict__ seeds, unsigned long long* __restrict__ stats,
+                                                    unsigned epoch)
+{
+    __shared__ unsigned wbad[4];
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int qblocks = nq_pad / 64;
+    const bool is_t = static_cast<int>(blockIdx.x) >= qblocks;
+    const float* x = is_t ? T : Q;
+    const int n = is_t ? nt : nq;
+    uint2* x8 = is_t ? T8 : Q8;
+    const int row0 = (is_t ? blockIdx.x - qblocks : blockIdx.x) * 64;
+    unsigned bad = 0u;
+    const int c0 = 8 * sub;
+    f32x4 ld[4][2];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {                          // all eight loads of a thread in flight together (see prep16)
+        const int row = row0 + it * 16 + grp;
+        const float* p = x + static_cast<size_t>(row < n ? row : n - 1) * dim;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int c = c0 + 4 * e < dim ? c0 + 4 * e : dim - 4;
+            ld[it][e] = *reinterpret_cast<const f32x4*>(p + c);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = row0 + it * 16 + grp;                 // < n_pad by construction
+        const bool live = row < n;
+        float s = 0.f;
+        bool okrow = true;
+        unsigned w[2] = {0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool col = live && c0 + (e & ~3) < dim;
+            const float v = ld[it][e >> 2][e & 3];
+            okrow &= !col || ((v == __builtin_rintf(v)) && v >= 0.f && v <= 255.f);
+            const float vc = __builtin_fminf(__builtin_fmaxf(v, 0.f), 255.f);      // (NaN -> 0; the row is flagged anyway)
+            const float c = col ? vc - 128.f : 0.f;
+            s = fmaf(c, c, s);                                // exact: 128 * 128^2 < 2^24
+            const unsigned b = col ? (static_cast<unsigned>(static_cast<int>(vc)) ^ 0x80u) : 0u;   // x - 128 as a signed byte
+            w[e >> 2] |= b << (8 * (e & 3));
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
+        if (!okrow) bad |= 2u;
+        x8[static_cast<size_t>(row) * (U8_DP / 8) + sub] = uint2{w[0], w[1]};
+        if (sub == 0) {
+            const int si = static_cast<int>(s);
+            if (is_t) {
+                seeds[seed_pos(row)] = live ? -(si >> 1) : U8_PAD_SEED;
+                if (live) tnorm[row] = s;                     // ||t - 128||^2 (an exact integer: the integer refinement's row term)
+            } else if (live) {
+                qnorm[row] = s;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bad |= static_cast<unsigned>(__shfl_xor(static_cast<int>(bad), o, 64));
+    if ((threadIdx.x & 63) == 0) wbad[threadIdx.x >> 6] = bad;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bad = wbad[0] | wbad[1] | wbad[2] | wbad[3];
+        if (bad) atomicMax(&stats[1], (static_cast<unsigned long long>(epoch) << 32) | 3ull);   // not u8-valued: scan exactly
     }
 }
 
@@ -427,8 +516,9 @@ struct KnnGeom {
     float embed_coef;         // truncation by the embedded id, times (||q||^2 + 2 max||t||^2)
     float eps_coef_gen;       // f16 route on general floats: rounding of the copies, same factor (SPEC S1c)
     float abs_gen;            // ... plus this many units of the SCALED accumulator (flushed subnormals, seed rounding)
+    int int_shift;            // u8 route: candidates are ints (w << int_shift) | id and qnorm holds ||q - 128||^2; else 0
 };
-enum { ROUTE_F32 = 0, ROUTE_F16_HINT = 1, ROUTE_AUTO = 2 };
+enum { ROUTE_F32 = 0, ROUTE_F16_HINT = 1, ROUTE_AUTO = 2, ROUTE_U8_HINT = 3 };
 
 // position of the r-th (0-based) set bit of m; r < popcount(m)
 __device__ __forceinline__ int nth_set_bit(unsigned long long m, int r)
@@ -546,8 +636,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void knn_
         const bool gen_off = static_cast<unsigned>(s3 >> 32) == epoch;          // the general-float f16 route withdrew
         general = route == ROUTE_AUTO && ineligible && !gen_off;
     }
-    const bool use16 = route == ROUTE_F16_HINT || (route == ROUTE_AUTO && (!ineligible || general));
-    const bool nonfinite = (flagged && (s1 & 1ull)) || (route == ROUTE_F16_HINT && ineligible);
+    const bool hinted = route == ROUTE_F16_HINT || route == ROUTE_U8_HINT;
+    const bool use16 = hinted || (route == ROUTE_AUTO && (!ineligible || general));
+    const bool nonfinite = (flagged && (s1 & 1ull)) || (hinted && ineligible);
     const KnnGeom g = use16 ? g16 : g32;
     float unscale = 1.f, eps_c = g.eps_coef, eps_abs = 0.f;
     bool unranked = false;
@@ -560,11 +651,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void knn_
             unranked = qs.unranked;
         }
     }
-    if (diag && lane == 0 && !ghost && q == 0) diag[2] = general ? 1u : (use16 ? 0u : 2u);
+    if (diag && lane == 0 && !ghost && q == 0) diag[2] = general ? 1u : (use16 ? (g.int_shift ? 3u : 0u) : 2u);
     const int slots = g.slots, tiles_per_split = g.tiles_per_split, rows_per_tile = g.rows_per_tile;
     const unsigned lid_mask = g.lid_mask;
     // window half-width: fp error of the coarse value + truncation by the embedded row id
-    const float eps = eps_c * (na + tmax) + g.embed_coef * (na + 2.f * tmax) + eps_abs;
+    // (u8 route: exact integers, the coarse value is d2 or d2 - 1)
+    const float eps = g.int_shift ? 1.f : eps_c * (na + tmax) + g.embed_coef * (na + 2.f * tmax) + eps_abs;
     const float* cv = g.cand + static_cast<size_t>(q) * slots;
     const int gshift = 31 - __clz(rows_per_tile >> 3);       // groups per tile = rows/8 = 2^gshift
 
@@ -578,7 +670,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void knn_
         const int s = lane + 64 * i;
         const float w = s < slots ? cv[s] : -KNN_INF;
         const float ws = GEN ? w * unscale : w;                                  // (a power of two: the id bits survive)
-        const float v = w > -1.0e38f ? fmaf(-2.f, ws, na) : KNN_INF;
+        float v = w > -1.0e38f ? fmaf(-2.f, ws, na) : KNN_INF;
+        if (g.int_shift) {                                                       // wave-uniform: integer candidates
+            const int wi = static_cast<int>(__float_as_uint(w)) >> g.int_shift;
+            v = (s < slots && wi > U8_PAD_SEED) ? fmaf(-2.f, static_cast<float>(wi), na) : KNN_INF;
+        }
         const unsigned gid2 = __float_as_uint(w) & lid_mask;   // (group id << 1) | lane half
         const unsigned gid = gid2 >> 1;
         const int split = s >> 2, hh = static_cast<int>(gid2 & 1u);      // s / KNN_C
@@ -752,6 +848,155 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void knn_
         }
     }
     if (tile == ntiles - 1 && tid == 0) *fz.n_out = prefix + cnt;
+}
+
+// ---------------------------------------------------------------------------------------------
+// u8 route refinement (round 3): one wave per query, ONE LANE PER CANDIDATE ROW.  For u8-valued data every partial sum
+// of the canonical f32 distance (SPEC S1) is an integer below 2^24, i.e. the canonical value IS the integer squared
+// distance, whatever the summation order — so the rows are re-evaluated on the centred byte copies the coarse pass
+// already made: d2 = ||q'||^2 + ||t'||^2 - 2 q'.t' with 32 v_dot4_i32_i8 per row (128 B per row instead of 512 B and
+// ~400 f32 operations), distance = sqrtf(float(d2)) (correctly rounded), key = (distance bits, index) as everywhere.
+// Candidate groups hold GROUP = 4, 8 or 16 rows (the coarse kernel's selection cost falls with the group size; here
+// 64 rows cost what one costs).  A wrong hint (bit 1 of stats[1]) sends every query to the canonical f32 scan.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int u8_row_d2(const uint4 (&qv)[U8_ROW16], const uint4* __restrict__ T8, int row, int qn,
+                                         const float* __restrict__ tnorm)
+{
+    const uint4* tp = T8 + static_cast<size_t>(row) * U8_ROW16;
+    uint4 tv[U8_ROW16];
+#pragma unroll
+    for (int i = 0; i < U8_ROW16; ++i) tv[i] = tp[i];
+    const int tn = static_cast<int>(tnorm[row]);
+    int d0 = 0, d1 = 0;
+#pragma unroll
+    for (int i = 0; i < U8_ROW16; ++i) {
+        d0 = __builtin_amdgcn_sdot4(static_cast<int>(qv[i].x), static_cast<int>(tv[i].x), d0, false);
+        d1 = __builtin_amdgcn_sdot4(static_cast<int>(qv[i].y), static_cast<int>(tv[i].y), d1, false);
+        d0 = __builtin_amdgcn_sdot4(static_cast<int>(qv[i].z), static_cast<int>(tv[i].z), d0, false);
+        d1 = __builtin_amdgcn_sdot4(static_cast<int>(qv[i].w), static_cast<int>(tv[i].w), d1, false);
+    }
+    return qn + tn - 2 * (d0 + d1);
+}
+
+// (amdgpu_num_sgpr: the query's 32 dwords ride in SGPRs; above 80 a CU admits 7 instead of 8 of these workgroups — see knn_l2_refine)
+template <int NS, int GROUP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void knn_l2_refine8(
+    const float* __restrict__ Q, const float* __restrict__ T, const uint4* __restrict__ Q8, const uint4* __restrict__ T8,
+    const float* __restrict__ qnorm, const float* __restrict__ tnorm, const int* __restrict__ cand,
+    const unsigned long long* __restrict__ stats, unsigned epoch, unsigned* __restrict__ diag, int nq, int nt, int dim, int k,
+    int slots, int tiles_per_split, pm_match* __restrict__ out)
+{
+    constexpr int GPB = 16 / GROUP;                          // groups per 32-row block and lane half
+    __shared__ int clist[4][64 * NS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    if (q >= nq) return;                                     // wave-uniform (no block barriers below)
+    const unsigned long long s1 = stats[1];
+    const bool wrong_hint = static_cast<unsigned>(s1 >> 32) == epoch;       // any flag: not u8-valued (or not finite)
+    if (diag && lane == 0 && q == 0) diag[2] = 3u;
+    const int qn = static_cast<int>(qnorm[q]);
+    const int* cv = cand + static_cast<size_t>(q) * slots;
+
+    // slot s = lane + 64*i: candidate (w << U8_SHIFT) | (group id << 1 | lane half); coarse squared distance
+    // d2a = ||q'||^2 - 2w = d2 or d2 - 1 of the group's best row
+    int val[NS], code[NS];
+    int m0 = 0x7FFFFFFF, m1 = 0x7FFFFFFF;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int s = lane + 64 * i;
+        const int c = s < slots ? cv[s] : I8_EMPTY;
+        const int wi = c >> U8_SHIFT;
+        const int v = wi > U8_PAD_SEED ? qn - 2 * wi : 0x7FFFFFFF;
+        const int gid2 = c & ((1 << U8_SHIFT) - 1);
+        const int gid = gid2 >> 1, hh = gid2 & 1;
+        const int split = s >> 2;
+        const int tile = gid / (4 * GPB), rem = gid % (4 * GPB);
+        val[i] = v;
+        // first row of the group's 32-row block | (group inside the block << 1) | lane half   (block rows are multiples of 32)
+        code[i] = ((split * tiles_per_split + tile) * H_TT + 32 * (rem / GPB)) | ((rem % GPB) << 1) | hh;
+        if (v < m1) { if (v < m0) { m1 = m0; m0 = v; } else { m1 = v; } }
+    }
+    static_assert(KNN_C == 4, "slot decoding assumes 4 entries per list");
+    int tau = 0x7FFFFFFF;
+    for (int round = 0; round < k; ++round) {
+        tau = static_cast<int>(pm::wave_min_u32(static_cast<unsigned>(m0) ^ 0x80000000u) ^ 0x80000000u);
+        const unsigned long long owners = __ballot(m0 == tau);
+        const int first = __ffsll(static_cast<long long>(owners)) - 1;
+        if (lane == first) { m0 = m1; m1 = 0x7FFFFFFF; }
+    }
+    const bool rescan = wrong_hint || tau == 0x7FFFFFFF;     // fewer than k ranked groups (nt < k, ...): scan everything
+    const int thr = rescan ? 0 : tau + 1;
+    if (diag && lane == 0) { if (rescan) atomicAdd(&diag[0], 1u); if (wrong_hint) diag[1] = 1u; }
+
+    Best2 b{~0ull, ~0ull, KNN_INF, KNN_INF};
+    if (wrong_hint) {                                        // canonical scan of the f32 rows (the hint only costs time)
+        const float* qp = Q + static_cast<size_t>(q) * dim;
+        for (int j = lane; j < nt; j += 64) {
+            const float d = __builtin_sqrtf(l2sqr_canonical<true>(qp, T + static_cast<size_t>(j) * dim, dim));
+            best2_insert(b, knn_key(d, j), d);
+        }
+    } else {
+        uint4 qv[U8_ROW16];                                  // the query's centred bytes (wave-uniform address)
+#pragma unroll
+        for (int i = 0; i < U8_ROW16; ++i) qv[i] = Q8[static_cast<size_t>(q) * U8_ROW16 + i];
+        auto take = [&](int row) {
+            const int d2 = u8_row_d2(qv, T8, row, qn, tnorm);
+            const float d = __builtin_sqrtf(static_cast<float>(d2));
+            best2_insert(b, knn_key(d, row), d);
+        };
+        if (rescan) {
+            for (int j = lane; j < nt; j += 64) take(j);
+        } else {
+            int total = 0;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                if (64 * i >= slots) break;                  // wave-uniform
+                const int s = lane + 64 * i;
+                const bool in = s < slots;
+                const int v = val[i];
+                // a list whose 4th entry is inside the window may have dropped candidates: scan its split instead
+                unsigned long long spilled = __ballot(in && (s & (KNN_C - 1)) == KNN_C - 1 && v <= thr);
+                const bool mine_spilled = (spilled >> (lane | (KNN_C - 1))) & 1ull;
+                const bool is_cand = in && v <= thr && !mine_spilled;
+                const unsigned long long cm = __ballot(is_cand);
+                if (is_cand) clist[wave][total + __popcll(cm & ((1ull << lane) - 1ull))] = code[i];
+                total += __popcll(cm);
+                if (diag && lane == 0 && spilled) atomicAdd(&diag[0], static_cast<unsigned>(__popcll(spilled)));
+                while (spilled) {                            // wave-uniform, rare
+                    const int split = (64 * i + __ffsll(static_cast<long long>(spilled)) - 1) / KNN_C;
+                    spilled &= spilled - 1ull;
+                    const int row_begin = split * tiles_per_split * H_TT;
+                    for (int lid = lane; lid < tiles_per_split * H_TT; lid += 64)
+                        if (row_begin + lid < nt) take(row_begin + lid);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int nrows = total * GROUP;
+            for (int r0 = 0; r0 < nrows; r0 += 64) {         // one row per lane
+                const int idx = r0 + lane;
+                if (idx < nrows) {
+                    const int cd = clist[wave][idx / GROUP];
+                    const int reg = ((cd >> 1) & 15) * GROUP + idx % GROUP;
+                    const int row = (cd & ~31) + (reg & 3) + 8 * (reg >> 2) + 4 * (cd & 1);
+                    if (row < nt) take(row);
+                }
+            }
+        }
+    }
+    for (int c = 0; c < k; ++c) {
+        const uint64_t best = wave_min_u64(b.k0);
+        const unsigned long long owners = __ballot(b.k0 == best);
+        const int first = __ffsll(static_cast<long long>(owners)) - 1;
+        const float dist = __shfl(b.d0, first, 64);
+        if (lane == first) { b.k0 = b.k1; b.d0 = b.d1; b.k1 = ~0ull; b.d1 = KNN_INF; }
+        pm_match m;
+        m.queryIdx = q;
+        m.imgIdx = 0;
+        if (best == ~0ull) { m.trainIdx = -1; m.distance = KNN_INF; }
+        else { m.trainIdx = static_cast<int>(static_cast<uint32_t>(best)); m.distance = dist; }
+        if (lane == 0) out[static_cast<size_t>(q) * k + c] = m;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1003,7 +1248,8 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
         const int rx = run_exact(ctx, dq, nq, dt, nt, dim, k, dout);
         return rx == PM_OK && fuse ? 1 : rx;                 // 1: done, but the caller still has to filter
     }
-    const int route = (flags & PM_KNN_FORCE_F32) ? ROUTE_F32 : (flags & PM_KNN_HINT_INTEGER) ? ROUTE_F16_HINT : ROUTE_AUTO;
+    int route = (flags & PM_KNN_FORCE_F32) ? ROUTE_F32 : (flags & PM_KNN_HINT_U8) ? ROUTE_U8_HINT :
+                (flags & PM_KNN_HINT_INTEGER) ? ROUTE_F16_HINT : ROUTE_AUTO;
     // automatic route: general floats rank on rounded f16 copies too (SPEC S1c); the f32-input pass is enqueued only when
     // forced (PM_KNN_FORCE_F32) or when PM_OPT_KNN_GENERAL_F16 = 1 keeps it as the automatic route's pass for such data
     const bool gen32 = route == ROUTE_AUTO && ctx->opts[PM_OPT_KNN_GENERAL_F16] == 1;
@@ -1038,9 +1284,13 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
         g32.embed_coef = static_cast<float>(static_cast<double>(1u << lid_bits32) * 1.1920928955078125e-7 * 1.01);
     }
     // ---- f16 route geometry: 128-row tiles, 256 queries per workgroup (4 waves x 64)
-    const int nq_pad = (nq + H_QB - 1) / H_QB * H_QB, nt_pad = (nt + H_TT - 1) / H_TT * H_TT;
+    // (u8 ring kernel in its 16-wave form, PM_OPT_KNN_F16_WAVES = 3: 512 queries per workgroup)
+    const int qb_wg = ((flags & PM_KNN_HINT_U8) && !(flags & PM_KNN_FORCE_F32) && ctx->opts[PM_OPT_KNN_RING] >= 2 &&
+                       ctx->opts[PM_OPT_KNN_U8_GROUP] != 1 && ctx->opts[PM_OPT_KNN_U8_GROUP] != 3 &&
+                       ctx->opts[PM_OPT_KNN_F16_WAVES] == 3) ? 512 : H_QB;
+    const int nq_pad = (nq + qb_wg - 1) / qb_wg * qb_wg, nt_pad = (nt + H_TT - 1) / H_TT * H_TT;
     {
-        const int nqb = nq_pad / H_QB;
+        const int nqb = nq_pad / qb_wg;
         const int ntiles = nt_pad / H_TT;
         // train splits sized for ONE workgroup per CU: with LDS-DMA staging a lone workgroup keeps the matrix pipe as busy as
         // two co-resident ones did with register staging (C3: 18.9 vs 19.0-21.7 us, 4096 x 4096: 10.0 vs 11.6 us), and half
@@ -1067,6 +1317,27 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
         g16.abs_gen = static_cast<float>(dim) / 4.f + 4.f;
         g16.embed_coef = static_cast<float>(static_cast<double>(1u << lid_bits16) * 1.1920928955078125e-7 * 1.01);
     }
+    // the seeded forms (round 3) of the two hint routes: LDS-DMA staging only, and the u8 route's integer candidates
+    // leave 9 bits for the id (<= 2048 train rows per split, which the split rule above keeps below 64 splits)
+    const int seeded_opt = ctx->opts[PM_OPT_KNN_SEEDED];
+    // (the u8 route's integer refinement writes k-NN records: the fused filter-in-refinement form stays on the f16 pass)
+    if (route == ROUTE_U8_HINT && (lid_bits16 > U8_SHIFT || (static_cast<long long>(nt_pad) + H_TT) * U8_DP >= 0x7FFFFFFFLL ||
+                                   seeded_opt == 1 || fuse != nullptr))
+        route = ROUTE_F16_HINT;                                 // u8-valued data satisfy the integer premise too
+    // rows per candidate group of the u8 route: PM_OPT_KNN_U8_GROUP 1 / 2 / 3 = 4 / 8 / 16 (0: 8)
+    const int u8_group = ctx->opts[PM_OPT_KNN_U8_GROUP] == 1 ? 4 : (ctx->opts[PM_OPT_KNN_U8_GROUP] == 3 ? 16 : 8);
+    // u8 refinement: integer re-evaluation on the byte copies (default) or the canonical f32 kernel (4-row groups only)
+    const bool u8_int_refine = !(ctx->opts[PM_OPT_KNN_U8_REFINE] == 1 && u8_group == 4);
+    // (f16 pass: the seeded form measured SLOWER than the seed chunk — C3 21.1 vs 18.7 us, 32k x 32k 199 vs 203 us: the four
+    // C-in reads per block cost what the ninth MFMA cost — so it runs only when PM_OPT_KNN_SEEDED = 2 asks for it)
+    const bool f16s = route == ROUTE_F16_HINT && seeded_opt == 2 &&
+                      (static_cast<long long>(nt_pad) + H_TT) * (F16S_ROW16 * 16) < 0x7FFFFFFFLL;
+    const bool u8r = route == ROUTE_U8_HINT;
+    if (u8r) {
+        g16.lid_mask = (1u << U8_SHIFT) - 1u;
+        g16.int_shift = U8_SHIFT;
+        g16.embed_coef = 0.f;
+    }
     if ((want32 && lid_bits32 > 16) || (want16 && lid_bits16 > 16)) {    // > 64k rows per lane stream
         const int rx = run_exact(ctx, dq, nq, dt, nt, dim, k, dout);
         return rx == PM_OK && fuse ? 1 : rx;
@@ -1076,12 +1347,14 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
     // interleave calls on one context are serialised by the stream.
     const size_t c32 = want32 ? sizeof(float) * static_cast<size_t>(nq) * g32.slots : 0;
     const size_t c16 = want16 ? sizeof(float) * static_cast<size_t>(nq) * g16.slots : 0;
-    const size_t qh = want16 ? sizeof(_Float16) * static_cast<size_t>(nq_pad) * H_ROW : 0;
-    const size_t th = want16 ? sizeof(_Float16) * static_cast<size_t>(nt_pad) * H_ROW : 0;
+    const size_t rowb = u8r ? U8_DP : sizeof(_Float16) * (f16s ? H_DP : H_ROW);   // bytes per row of the coarse copies
+    const size_t qh = want16 ? rowb * static_cast<size_t>(nq_pad) : 0;
+    const size_t th = want16 ? rowb * static_cast<size_t>(nt_pad) : 0;
+    const size_t sdb = (u8r || f16s) ? 4 * static_cast<size_t>(nt_pad + H_TT) : 0;       // seeds (+ one tile of slack)
     const size_t pkb = fuse ? sizeof(unsigned long long) * static_cast<size_t>(nq) : 0;
     const size_t need = pm::align_up(sizeof(float) * nq, 256) + pm::align_up(sizeof(float) * nt, 256) +
                         pm::align_up(c32, 256) + pm::align_up(c16, 256) + pm::align_up(qh, 256) + pm::align_up(th, 256) +
-                        pm::align_up(pkb, 256) + 2048;
+                        pm::align_up(sdb, 256) + pm::align_up(pkb, 256) + 2048;
     int rc = pm::arena_reserve(ctx, need);
     if (rc != PM_OK) return rc;
     pm::arena_reset(ctx);
@@ -1091,7 +1364,8 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
     float* cval16 = want16 ? static_cast<float*>(pm::arena_take(ctx, c16)) : nullptr;
     _Float16* Qh = want16 ? static_cast<_Float16*>(pm::arena_take(ctx, qh)) : nullptr;
     _Float16* Th = want16 ? static_cast<_Float16*>(pm::arena_take(ctx, th)) : nullptr;
-    PM_REQUIRE(qnorm && tnorm && (!want32 || cval32) && (!want16 || (cval16 && Qh && Th)), PM_E_NOMEM,
+    void* seeds = sdb ? pm::arena_take(ctx, sdb) : nullptr;
+    PM_REQUIRE(qnorm && tnorm && (!want32 || cval32) && (!want16 || (cval16 && Qh && Th)) && (!sdb || seeds), PM_E_NOMEM,
                "scratch arena too small");
     KnnFuse fz{};
     if (fuse) {
@@ -1117,9 +1391,16 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
     }
     {
         pm::ScopedKernelTime t(ctx, "knn_l2_prep");
-        if (want16)
-            hipLaunchKernelGGL(knn_l2_prep16, dim3(nq_pad / 64 + nt_pad / 64), dim3(256), 0, ctx->stream, dq, nq, nq_pad,
-                               dt, nt, nt_pad, dim, qnorm, tnorm, Qh, Th, stats, epoch);
+        if (u8r)
+            hipLaunchKernelGGL(knn_l2_prep8, dim3(nq_pad / 64 + nt_pad / 64), dim3(256), 0, ctx->stream, dq, nq, nq_pad, dt,
+                               nt, nt_pad, dim, qnorm, tnorm, reinterpret_cast<uint2*>(Qh), reinterpret_cast<uint2*>(Th),
+                               static_cast<int*>(seeds), stats, epoch);
+        else if (f16s)
+            hipLaunchKernelGGL(knn_l2_prep16<true>, dim3(nq_pad / 64 + nt_pad / 64), dim3(256), 0, ctx->stream, dq, nq, nq_pad,
+                               dt, nt, nt_pad, dim, qnorm, tnorm, Qh, Th, static_cast<float*>(seeds), stats, epoch);
+        else if (want16)
+            hipLaunchKernelGGL(knn_l2_prep16<false>, dim3(nq_pad / 64 + nt_pad / 64), dim3(256), 0, ctx->stream, dq, nq, nq_pad,
+                               dt, nt, nt_pad, dim, qnorm, tnorm, Qh, Th, nullptr, stats, epoch);
         else
             hipLaunchKernelGGL(knn_l2_prep, dim3((nq + 63) / 64 + (nt + 63) / 64), dim3(256), 0, ctx->stream, dq, nq, dt,
                                nt, dim, qnorm, tnorm, stats, epoch);
@@ -1132,7 +1413,15 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
             hipLaunchKernelGGL(knn_gen_off, dim3(1), dim3(64), 0, ctx->stream, stats, epoch);
         PM_HIP_CHECK(hipGetLastError());
     }
-    if (want16) {
+    if (u8r) {
+        rc = launch_coarse_u8(ctx, Qh, Th, static_cast<const int*>(seeds), nq, nq_pad, nt, splits16, g16.tiles_per_split,
+                              reinterpret_cast<int*>(cval16), g16.slots, u8_group, ctx->opts[PM_OPT_KNN_RING] >= 2);
+        if (rc != PM_OK) return rc;
+    } else if (f16s) {
+        rc = launch_coarse_f16s(ctx, Qh, Th, static_cast<const float*>(seeds), nq, nq_pad, nt, splits16, g16.tiles_per_split,
+                                ~g16.lid_mask, cval16, g16.slots);
+        if (rc != PM_OK) return rc;
+    } else if (want16) {
         rc = launch_coarse_f16(ctx, Qh, Th, nq, nq_pad, nt, splits16, g16.tiles_per_split, ~g16.lid_mask, cval16,
                                g16.slots, stats, epoch, route == ROUTE_AUTO ? 1 : 0);
         if (rc != PM_OK) return rc;
@@ -1141,6 +1430,21 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
         rc = launch_coarse_f32(ctx, dq, nq, dt, nt, dim, tnorm, splits32, g32.tiles_per_split, ~g32.lid_mask, cval32,
                                g32.slots, stats, epoch, route == ROUTE_AUTO ? 1 : 0);
         if (rc != PM_OK) return rc;
+    }
+    if (u8r && u8_int_refine) {
+        pm::ScopedKernelTime t(ctx, "knn_l2_refine");
+#define PM_R8(NS_, GROUP_)                                                                                                 \
+    hipLaunchKernelGGL((knn_l2_refine8<NS_, GROUP_>), dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, dq, dt,                \
+                       reinterpret_cast<const uint4*>(Qh), reinterpret_cast<const uint4*>(Th), qnorm, tnorm,               \
+                       reinterpret_cast<const int*>(cval16), stats, epoch, diag, nq, nt, dim, k, g16.slots, g16.tiles_per_split, dout)
+#define PM_R8G(NS_) do { if (u8_group == 4) PM_R8(NS_, 4); else if (u8_group == 8) PM_R8(NS_, 8); else PM_R8(NS_, 16); } while (0)
+        if (g16.slots <= 64) PM_R8G(1);
+        else if (g16.slots <= 128) PM_R8G(2);
+        else PM_R8G(4);
+#undef PM_R8G
+#undef PM_R8
+        PM_HIP_CHECK(hipGetLastError());
+        return PM_OK;
     }
     {
         pm::ScopedKernelTime t(ctx, "knn_l2_refine");

@@ -41,6 +41,43 @@ constexpr int I8_GROUP_ROWS = 8;
 constexpr int I8_SHIFT = 16;             // candidate = (dot << 16) | group id, |dot| <= 256
 constexpr int I8_EMPTY = static_cast<int>(0x80000000u);   // an unfilled list entry
 
+// Seeded routes (round 3): the per-row term -||t||^2/2 no longer rides a k-chunk of its own through the matrix pipe; it
+// STARTS the accumulators.  A 32-row block's 32 seeds are kept in the order of the 32x32 C/D layout ("seed order":
+// position 16*h + reg <-> row (reg&3) + 8*(reg>>2) + 4*h of the block), so a lane's 16 C-in registers are four
+// ds_read_b128 of a 512-byte per-tile array that is staged by one more LDS-DMA piece.  Every issued MFMA is then
+// algorithmic work (2*D flop per pair).
+//   u8 route   u8-valued descriptors (OpenCV SIFT: 0..255) centred to x - 128 and ranked on v_mfma_i32_32x32x32_i8:
+//              128-byte rows = 4 k-chunks, exact integers; seed = -(||t - 128||^2 >> 1), so the coarse squared
+//              distance ||q'||^2 - 2w is d2 or d2 - 1 (the refinement's window carries the unit);
+//   f16s route integer-valued descriptors with |x| <= 361 on v_mfma_f32_32x32x16_f16: 256-byte rows = 8 chunks.
+constexpr int U8_DP = 128;              // data columns (bytes) per row
+constexpr int U8_NCH = 4;               // k-chunks of 32 bytes
+constexpr int U8_ROW16 = 8;             // 16-byte units per global row
+constexpr int U8_LDS_ROW16 = 9;         // 144-byte LDS rows: 16 rows of a lane group hit 16 different 16-byte slots
+constexpr int U8_SHIFT = 9;             // candidate = (w << 9) | (group id << 1 | lane half); |w| < 2^22
+constexpr int U8_PAD_SEED = -(1 << 22); // seed of the rows padding the last tile: below every real w (>= -3.13e6)
+constexpr int F16S_NCH = 8;
+constexpr int F16S_ROW16 = 16;
+constexpr int F16S_LDS_ROW16 = 17;
+constexpr int SEED_TILE_BYTES = H_TT * 4;       // one tile's seeds (128 x 4 B), seed order inside each 32-row block
+
+// position of train row `row` (global index) in the seed array
+__host__ __device__ inline int seed_pos(int row)
+{
+    const int i = row & 31;
+    return (row & ~31) + 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3);
+}
+
+// Enqueue the seeded coarse passes.  Q8/T8: nq_pad x 128 / nt_pad x 128 centred bytes; Qh/Th: n_pad x 128 halfs;
+// seeds: nt_pad (+ H_TT slack) 4-byte seeds in seed order.  Candidates: u8 route int (w << U8_SHIFT) | id, f16s
+// route float with the id in the low mantissa bits (keep_mask as on the f16 route).
+// group_rows: rows per candidate group (4, 8 or 16); ring: ring of 8 LDS tile buffers with counted waits instead of the
+// double-buffered form.
+int launch_coarse_u8(pm_ctx* ctx, const void* Q8, const void* T8, const int* seeds, int nq, int nq_pad, int nt, int splits,
+                     int tiles_per_split, int* cval, int slots, int group_rows, bool ring);
+int launch_coarse_f16s(pm_ctx* ctx, const _Float16* Qh, const _Float16* Th, const float* seeds, int nq, int nq_pad, int nt,
+                       int splits, int tiles_per_split, unsigned keep_mask, float* cval, int slots);
+
 // Enqueue the f32-MFMA coarse pass (dim % 4 == 0, dim <= 128).  only_if_ineligible != 0: the
 // kernel runs only when prep16 flagged the data as not f16-eligible (auto route).
 int launch_coarse_f32(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt, int dim, const float* tnorm,

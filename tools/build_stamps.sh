@@ -17,3 +17,16 @@ echo built $B/abl/libpm_rfstamps.so
 /opt/rocm/bin/hipcc $F -DRF_SCALAR_FMA=1 -x hip -c tools/ablation/ransac_fused_stamps.hip -o /tmp/rf_stamps2.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $B/abl/libpm_rfstamps_scalar.so /tmp/rf_stamps2.o $objs -ldl
 echo built $B/abl/libpm_rfstamps_scalar.so
+# coarse kNN kernels with stamps (u8 ring kernel): knn_coarse.o swapped for tools/ablation/knn_coarse_stamps.hip
+objs2=$(ls $B/*.o | grep -v '/knn_coarse\.o$')
+/opt/rocm/bin/hipcc $F -ffinite-math-only -x hip -c tools/ablation/knn_coarse_stamps.hip -o /tmp/knn_stamps.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $B/abl/libpm_knnstamps.so /tmp/knn_stamps.o $objs2 -ldl
+echo built $B/abl/libpm_knnstamps.so
+# timing-only ablations of the same (outputs wrong): no selection / no LDS operand reads / neither / no barrier
+for v in "NO_EPI" "NO_LDSREAD" "NO_EPI NO_LDSREAD" "NO_BARRIER" "NO_EPI NO_LDSREAD NO_BARRIER NO_STAGE"; do
+  name=$(echo "$v" | tr -d '_' | tr ' ' '_')
+  defs=""; for w in $v; do defs="$defs -DABL_$w=1"; done
+  /opt/rocm/bin/hipcc $F -ffinite-math-only $defs -x hip -c tools/ablation/knn_coarse_stamps.hip -o /tmp/knn_stamps_v.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $B/abl/libpm_knnstamps_$name.so /tmp/knn_stamps_v.o $objs2 -ldl
+  echo built $B/abl/libpm_knnstamps_$name.so
+done
