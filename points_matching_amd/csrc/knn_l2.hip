@@ -878,35 +878,62 @@ __device__ __forceinline__ int u8_row_d2(const uint4 (&qv)[U8_ROW16], const uint
     return qn + tn - 2 * (d0 + d1);
 }
 
-// (amdgpu_num_sgpr: the query's 32 dwords ride in SGPRs; above 80 a CU admits 7 instead of 8 of these workgroups — see knn_l2_refine)
+// FOUR queries per wave, one 16-lane row each: the candidate slots of a query (32 at config C3) never filled a wave, and
+// the first form of this kernel (one wave per query, ~300 instructions, like knn_l2_refine) was issue-bound at ~5 us for
+// 8192 queries.  Here the k-th-smallest search and the final top-k are 4-step DPP reductions inside a row (row_ror: no
+// cross-row traffic, no v_readlane) shared by four queries, and the usual two candidate groups of 8 rows are exactly
+// one row of lanes.  A query with an overflowing list, fewer than k ranked groups or a wrong hint scans all train rows
+// (rare; 16 lanes wide).
+__device__ __forceinline__ unsigned row_min_u32(unsigned v)          // minimum over the lane's 16-lane row, in every lane of it
+{
+    v = min(v, pm::dpp_u32<0x121>(v));
+    v = min(v, pm::dpp_u32<0x122>(v));
+    v = min(v, pm::dpp_u32<0x124>(v));
+    v = min(v, pm::dpp_u32<0x128>(v));
+    return v;
+}
+__device__ __forceinline__ unsigned long long row_min_u64(unsigned long long v)
+{
+    const unsigned hi = static_cast<unsigned>(v >> 32), lo = static_cast<unsigned>(v);
+    const unsigned mh = row_min_u32(hi);
+    const unsigned ml = row_min_u32(hi == mh ? lo : 0xFFFFFFFFu);
+    return (static_cast<unsigned long long>(mh) << 32) | ml;
+}
+
 template <int NS, int GROUP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void knn_l2_refine8(
+__global__ __launch_bounds__(256) void knn_l2_refine8(
     const float* __restrict__ Q, const float* __restrict__ T, const uint4* __restrict__ Q8, const uint4* __restrict__ T8,
     const float* __restrict__ qnorm, const float* __restrict__ tnorm, const int* __restrict__ cand,
     const unsigned long long* __restrict__ stats, unsigned epoch, unsigned* __restrict__ diag, int nq, int nt, int dim, int k,
     int slots, int tiles_per_split, pm_match* __restrict__ out)
 {
     constexpr int GPB = 16 / GROUP;                          // groups per 32-row block and lane half
-    __shared__ int clist[4][64 * NS];
+    constexpr int IMAX = 0x7FFFFFFF;
+    __shared__ int clist[4][4][16 * NS];                     // [wave][query of the wave][candidate]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
-    if (q >= nq) return;                                     // wave-uniform (no block barriers below)
+    const int qi = lane >> 4, l = lane & 15;
+    const int q = blockIdx.x * 16 + wave * 4 + qi;
+    const bool live = q < nq;
+    const int qc = live ? q : nq - 1;                        // rows past the last query shadow it (no early exit: DPP rows stay whole)
     const unsigned long long s1 = stats[1];
     const bool wrong_hint = static_cast<unsigned>(s1 >> 32) == epoch;       // any flag: not u8-valued (or not finite)
-    if (diag && lane == 0 && q == 0) diag[2] = 3u;
-    const int qn = static_cast<int>(qnorm[q]);
-    const int* cv = cand + static_cast<size_t>(q) * slots;
+    if (diag && threadIdx.x == 0 && blockIdx.x == 0) diag[2] = 3u;
+    const int qn = static_cast<int>(qnorm[qc]);
+    const int* cv = cand + static_cast<size_t>(qc) * slots;
+    uint4 qv[U8_ROW16];                                      // the query's centred bytes (one address per row of lanes)
+#pragma unroll
+    for (int i = 0; i < U8_ROW16; ++i) qv[i] = Q8[static_cast<size_t>(qc) * U8_ROW16 + i];
 
-    // slot s = lane + 64*i: candidate (w << U8_SHIFT) | (group id << 1 | lane half); coarse squared distance
+    // slot s = l + 16*i: candidate (w << U8_SHIFT) | (group id << 1 | lane half); coarse squared distance
     // d2a = ||q'||^2 - 2w = d2 or d2 - 1 of the group's best row
     int val[NS], code[NS];
-    int m0 = 0x7FFFFFFF, m1 = 0x7FFFFFFF;
+    int m0 = IMAX, m1 = IMAX;
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
-        const int s = lane + 64 * i;
+        const int s = l + 16 * i;
         const int c = s < slots ? cv[s] : I8_EMPTY;
         const int wi = c >> U8_SHIFT;
-        const int v = wi > U8_PAD_SEED ? qn - 2 * wi : 0x7FFFFFFF;
+        const int v = wi > U8_PAD_SEED ? qn - 2 * wi : IMAX;
         const int gid2 = c & ((1 << U8_SHIFT) - 1);
         const int gid = gid2 >> 1, hh = gid2 & 1;
         const int split = s >> 2;
@@ -917,85 +944,74 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void knn_
         if (v < m1) { if (v < m0) { m1 = m0; m0 = v; } else { m1 = v; } }
     }
     static_assert(KNN_C == 4, "slot decoding assumes 4 entries per list");
-    int tau = 0x7FFFFFFF;
-    for (int round = 0; round < k; ++round) {
-        tau = static_cast<int>(pm::wave_min_u32(static_cast<unsigned>(m0) ^ 0x80000000u) ^ 0x80000000u);
-        const unsigned long long owners = __ballot(m0 == tau);
-        const int first = __ffsll(static_cast<long long>(owners)) - 1;
-        if (lane == first) { m0 = m1; m1 = 0x7FFFFFFF; }
+    int tau = IMAX;
+    for (int round = 0; round < k; ++round) {                // k <= 2
+        tau = static_cast<int>(row_min_u32(static_cast<unsigned>(m0) ^ 0x80000000u) ^ 0x80000000u);
+        const unsigned owners = static_cast<unsigned>(__ballot(m0 == tau) >> (16 * qi)) & 0xFFFFu;
+        if (l == __ffs(static_cast<int>(owners)) - 1) { m0 = m1; m1 = IMAX; }
     }
-    const bool rescan = wrong_hint || tau == 0x7FFFFFFF;     // fewer than k ranked groups (nt < k, ...): scan everything
-    const int thr = rescan ? 0 : tau + 1;
-    if (diag && lane == 0) { if (rescan) atomicAdd(&diag[0], 1u); if (wrong_hint) diag[1] = 1u; }
+    bool full = wrong_hint || tau == IMAX;                   // fewer than k ranked groups (nt < k, ...): scan everything
+    const int thr = tau == IMAX ? 0 : tau + 1;
+
+    int total = 0;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        if (16 * i >= slots) break;                          // wave-uniform
+        const int s = l + 16 * i;
+        const bool in = s < slots && !full;
+        const int v = val[i];
+        // a list whose 4th entry is inside the window may have dropped candidates: that query scans everything
+        const unsigned spilled = static_cast<unsigned>(__ballot(in && (s & (KNN_C - 1)) == KNN_C - 1 && v <= thr) >> (16 * qi)) & 0xFFFFu;
+        const bool is_cand = in && v <= thr;
+        const unsigned rm = static_cast<unsigned>(__ballot(is_cand) >> (16 * qi)) & 0xFFFFu;
+        if (is_cand) clist[wave][qi][total + __popc(rm & ((1u << l) - 1u))] = code[i];
+        total += __popc(rm);
+        if (spilled) full = true;
+    }
+    if (diag && l == 0 && live && full) { atomicAdd(&diag[0], 1u); if (wrong_hint) diag[1] = 1u; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 
     Best2 b{~0ull, ~0ull, KNN_INF, KNN_INF};
-    if (wrong_hint) {                                        // canonical scan of the f32 rows (the hint only costs time)
-        const float* qp = Q + static_cast<size_t>(q) * dim;
-        for (int j = lane; j < nt; j += 64) {
-            const float d = __builtin_sqrtf(l2sqr_canonical<true>(qp, T + static_cast<size_t>(j) * dim, dim));
-            best2_insert(b, knn_key(d, j), d);
+    auto take = [&](int row) {
+        const int d2 = u8_row_d2(qv, T8, row, qn, tnorm);
+        const float d = __builtin_sqrtf(static_cast<float>(d2));
+        best2_insert(b, knn_key(d, row), d);
+    };
+    const int nrows = full ? 0 : total * GROUP;
+    for (int r0 = 0; __any(r0 < nrows); r0 += 16) {          // one row per lane, 16 per query and pass
+        const int idx = r0 + l;
+        if (idx < nrows) {
+            const int cd = clist[wave][qi][idx / GROUP];
+            const int reg = ((cd >> 1) & 15) * GROUP + idx % GROUP;
+            const int row = (cd & ~31) + (reg & 3) + 8 * (reg >> 2) + 4 * (cd & 1);
+            if (row < nt) take(row);
         }
-    } else {
-        uint4 qv[U8_ROW16];                                  // the query's centred bytes (wave-uniform address)
-#pragma unroll
-        for (int i = 0; i < U8_ROW16; ++i) qv[i] = Q8[static_cast<size_t>(q) * U8_ROW16 + i];
-        auto take = [&](int row) {
-            const int d2 = u8_row_d2(qv, T8, row, qn, tnorm);
-            const float d = __builtin_sqrtf(static_cast<float>(d2));
-            best2_insert(b, knn_key(d, row), d);
-        };
-        if (rescan) {
-            for (int j = lane; j < nt; j += 64) take(j);
+    }
+    if (__any(full)) {                                       // rare: 16 lanes walk all train rows of such a query
+        if (wrong_hint) {                                    // canonical scan of the f32 rows (the hint only costs time)
+            const float* qp = Q + static_cast<size_t>(qc) * dim;
+            for (int j = l; j < nt; j += 16) {
+                const float d = __builtin_sqrtf(l2sqr_canonical<true>(qp, T + static_cast<size_t>(j) * dim, dim));
+                best2_insert(b, knn_key(d, j), d);
+            }
         } else {
-            int total = 0;
-#pragma unroll
-            for (int i = 0; i < NS; ++i) {
-                if (64 * i >= slots) break;                  // wave-uniform
-                const int s = lane + 64 * i;
-                const bool in = s < slots;
-                const int v = val[i];
-                // a list whose 4th entry is inside the window may have dropped candidates: scan its split instead
-                unsigned long long spilled = __ballot(in && (s & (KNN_C - 1)) == KNN_C - 1 && v <= thr);
-                const bool mine_spilled = (spilled >> (lane | (KNN_C - 1))) & 1ull;
-                const bool is_cand = in && v <= thr && !mine_spilled;
-                const unsigned long long cm = __ballot(is_cand);
-                if (is_cand) clist[wave][total + __popcll(cm & ((1ull << lane) - 1ull))] = code[i];
-                total += __popcll(cm);
-                if (diag && lane == 0 && spilled) atomicAdd(&diag[0], static_cast<unsigned>(__popcll(spilled)));
-                while (spilled) {                            // wave-uniform, rare
-                    const int split = (64 * i + __ffsll(static_cast<long long>(spilled)) - 1) / KNN_C;
-                    spilled &= spilled - 1ull;
-                    const int row_begin = split * tiles_per_split * H_TT;
-                    for (int lid = lane; lid < tiles_per_split * H_TT; lid += 64)
-                        if (row_begin + lid < nt) take(row_begin + lid);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const int nrows = total * GROUP;
-            for (int r0 = 0; r0 < nrows; r0 += 64) {         // one row per lane
-                const int idx = r0 + lane;
-                if (idx < nrows) {
-                    const int cd = clist[wave][idx / GROUP];
-                    const int reg = ((cd >> 1) & 15) * GROUP + idx % GROUP;
-                    const int row = (cd & ~31) + (reg & 3) + 8 * (reg >> 2) + 4 * (cd & 1);
-                    if (row < nt) take(row);
-                }
-            }
+            for (int j0 = 0; j0 < nt; j0 += 16)
+                if (full && j0 + l < nt) take(j0 + l);
         }
     }
     for (int c = 0; c < k; ++c) {
-        const uint64_t best = wave_min_u64(b.k0);
-        const unsigned long long owners = __ballot(b.k0 == best);
-        const int first = __ffsll(static_cast<long long>(owners)) - 1;
-        const float dist = __shfl(b.d0, first, 64);
-        if (lane == first) { b.k0 = b.k1; b.d0 = b.d1; b.k1 = ~0ull; b.d1 = KNN_INF; }
+        const uint64_t best = row_min_u64(b.k0);
+        const unsigned owners = static_cast<unsigned>(__ballot(b.k0 == best) >> (16 * qi)) & 0xFFFFu;
+        const int first = __ffs(static_cast<int>(owners)) - 1;
+        const float dist = __shfl(b.d0, 16 * qi + first, 64);
+        if (l == first) { b.k0 = b.k1; b.d0 = b.d1; b.k1 = ~0ull; b.d1 = KNN_INF; }
         pm_match m;
         m.queryIdx = q;
         m.imgIdx = 0;
         if (best == ~0ull) { m.trainIdx = -1; m.distance = KNN_INF; }
         else { m.trainIdx = static_cast<int>(static_cast<uint32_t>(best)); m.distance = dist; }
-        if (lane == 0) out[static_cast<size_t>(q) * k + c] = m;
+        if (l == 0 && live) out[static_cast<size_t>(q) * k + c] = m;
     }
 }
 
@@ -1434,13 +1450,15 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
     if (u8r && u8_int_refine) {
         pm::ScopedKernelTime t(ctx, "knn_l2_refine");
 #define PM_R8(NS_, GROUP_)                                                                                                 \
-    hipLaunchKernelGGL((knn_l2_refine8<NS_, GROUP_>), dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, dq, dt,                \
+    hipLaunchKernelGGL((knn_l2_refine8<NS_, GROUP_>), dim3((nq + 15) / 16), dim3(256), 0, ctx->stream, dq, dt,              \
                        reinterpret_cast<const uint4*>(Qh), reinterpret_cast<const uint4*>(Th), qnorm, tnorm,               \
                        reinterpret_cast<const int*>(cval16), stats, epoch, diag, nq, nt, dim, k, g16.slots, g16.tiles_per_split, dout)
 #define PM_R8G(NS_) do { if (u8_group == 4) PM_R8(NS_, 4); else if (u8_group == 8) PM_R8(NS_, 8); else PM_R8(NS_, 16); } while (0)
-        if (g16.slots <= 64) PM_R8G(1);
-        else if (g16.slots <= 128) PM_R8G(2);
-        else PM_R8G(4);
+        if (g16.slots <= 16) PM_R8G(1);                      // slots of a query per lane of its 16-lane row
+        else if (g16.slots <= 32) PM_R8G(2);
+        else if (g16.slots <= 64) PM_R8G(4);
+        else if (g16.slots <= 128) PM_R8G(8);
+        else PM_R8G(16);
 #undef PM_R8G
 #undef PM_R8
         PM_HIP_CHECK(hipGetLastError());
