@@ -5,16 +5,19 @@ Workload (BASELINE.json configs[2], "C3"): 8k x 8k SIFT-128 float descriptors, b
 2-NN + ratio test (0.8), then 10 000-hypothesis RANSAC-F (normalised 8-point, Sampson, tau = 1 px)
 on the ~2.3k surviving matches.  It carries BOTH halves of BASELINE.json's metric
 ("descriptor-pair distances/s + RANSAC hypotheses/s") and fits one GPU; configs[1] (2k x 2k) is
-launch-latency sized and is covered as a parity test instead.
+launch-latency sized and is covered as a parity test and as `--workload c2`.
 
 One step = one pass of the path over one image pair, everything resident in HBM:
-  pm_bf_knn_l2_ratio_dev (2-NN + ratio test + compaction + gather) -> pm_ransac_run_dev (one launch: sample, solve,
-  score, pick, mask);  N>1: -> all-gather of the survivor blocks -> pm_ransac_shard_parts_dev -> all-gather of the
-  80-byte (key, F) records -> pm_ransac_finish_parts_dev (F + inlier mask of the winner on every rank)
-N GPUs (weak scaling): rank r matches its own 8k query rows against the replicated 8k train
-rows (global problem = N*8k x 8k), the survivors are all-gathered (RCCL), every rank scores its
-shard of the 10k hypothesis ids over ALL gathered correspondences, one all-reduce(max) of the
-packed (inliers, ~id) key picks the global winner, and every rank re-derives the same F + mask.
+  pm_bf_knn_l2_ratio_dev (prep + coarse matrix-core pass + refinement, then the ratio test + compaction + gather as its
+  own launch) -> pm_ransac_run_dev (one launch: sample, solve, score, pick, mask).
+N GPUs (weak scaling, one process per GPU): rank r matches its own 8k query rows against the replicated 8k train rows
+(global problem = N*8k x 8k) straight into its slot of the gathered survivor buffer -> all-gather #1 of the survivor
+blocks (RCCL, in place) -> pm_ransac_shard_parts_dev: the rank's shard of the 10k hypothesis ids over ALL gathered
+correspondences, one 80-byte (key, F) record -> all-gather #2 of the records (the arg-max all-reduce with its payload) ->
+pm_ransac_finish_parts_dev: every rank takes the record with the largest key and writes F + the inlier mask (nobody
+re-solves, nothing is broadcast).  The N > 1 step is software-pipelined: pair i+1's matcher is enqueued on a second stream
+while pair i sits in its two all-gathers and RANSAC (`--pipeline 0` runs the pairs strictly one after the other); every
+collective is also timed by itself (`collectives`).
 
 `value` = descriptor-pair distances/s of the matching stage (N*M*ranks / match-stage time);
 the RANSAC half of the metric is reported next to it (`ransac.hyp_per_s`, with N_m).
@@ -46,7 +49,7 @@ def _kernel_source_sha():
 
 def pmc_traffic(key, nq, nt):
     """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from inside this process: the figure
-    comes from the committed rocprofv3 --pmc passes (profiles/r02_traffic.json: FETCH_SIZE / WRITE_SIZE in separate
+    comes from the committed rocprofv3 --pmc passes (profiles/r03_traffic.json: FETCH_SIZE / WRITE_SIZE in separate
     runs, gfx950 correction applied) and is used ONLY when that file is stamped with the hash of the kernel sources
     it was measured on and this is exactly the profiled workload; otherwise null."""
     try:
@@ -56,7 +59,8 @@ def pmc_traffic(key, nq, nt):
             return None
     except (OSError, ValueError, KeyError):
         return None
-    want = {"c3:knn_l2_mfma_f16": (8192, 8192), "c3:knn_l2_mfma_u8": (8192, 8192), "c3:knn_l2_mfma_f16s": (8192, 8192), "c3_f32:knn_l2_mfma": (8192, 8192), "c4:knn_hamming_mfma_i8": (32768, 32768)}
+    want = {"c3:knn_l2_mfma_f16": (8192, 8192), "c3:knn_l2_mfma_u8": (8192, 8192), "c3:knn_l2_mfma_f16s": (8192, 8192), "c3_f32:knn_l2_mfma": (8192, 8192), "c4:knn_hamming_mfma_i8": (32768, 32768),
+            "l32k:knn_l2_mfma_u8": (32768, 32768), "l32k:knn_l2_mfma_f16": (32768, 32768)}
     if key in t and want.get(key) == (nq, nt):
         return t[key]["traffic_bytes"]
     return None
@@ -188,7 +192,12 @@ def main():
                     help="N > 1: weak = every rank matches its own nq query rows (global problem N*nq x nt, the default); "
                          "strong = ONE nq x nt problem, query rows and hypothesis ids both cut N ways (BASELINE config 4 is "
                          "`--workload c4 --scaling strong`)")
-    ap.add_argument("--sustain-seconds", type=float, default=0.5,
+    ap.add_argument("--pipeline", type=int, default=-1, choices=[-1, 0, 1],
+                    help="software-pipeline consecutive pairs over two streams (pair i+1's matcher while pair i is in its "
+                         "exchanges / RANSAC): -1 = on for N > 1 (and --exercise-exchange), off for one GPU; the serial figure is "
+                         "reported next to it either way")
+    ap.add_argument("--no-large", action="store_true", help="skip the 32k x 32k roofline leg of the matcher")
+    ap.add_argument("--sustain-seconds", type=float, default=2.0,
                     help="after the K timed steps: back-to-back steps for at least this long (clock-sustained figure)")
     ap.add_argument("--pairs", type=int, default=256, help="c5: image pairs in the whole job")
     ap.add_argument("--lanes", type=int, default=3, help="c5: streams (lanes) per GPU")
@@ -282,116 +291,187 @@ def main():
     stream = torch.cuda.Stream(device=dev)      # a real (non-null) stream shared by torch and the library
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
+    # a second context + stream: the exchange / RANSAC half of a pipelined step
+    ctx_b, stream_b = [], []
+    for _ in range(1):
+        cb = pm.Context(local_rank)
+        cb.set_option(pm.api.PM_OPT_RANSAC_PATH, args.ransac_path)
+        sb = torch.cuda.Stream(device=dev)
+        cb.set_stream(sb.cuda_stream)
+        ctx_b.append(cb)
+        stream_b.append(sb)
+    pipelined = multi if args.pipeline < 0 else bool(args.pipeline)
 
     d_q = torch.from_numpy(np.ascontiguousarray(w["q"])).to(dev)
     d_t = torch.from_numpy(np.ascontiguousarray(w["t"])).to(dev)
     d_kp1 = torch.from_numpy(np.ascontiguousarray(w["kp1"])).to(dev)
     d_kp2 = torch.from_numpy(np.ascontiguousarray(w["kp2"])).to(dev)
-    d_knn = torch.empty((nq, K, 4), dtype=torch.int32, device=dev)
-    d_good = torch.empty((nq, 4), dtype=torch.int32, device=dev)
-    # One contiguous "survivor block" per rank: [count (int32) + 3 pad words | xy1: nq x 2 f32 | xy2: nq x 2 f32].
-    # The filter writes straight into it, so the N>1 exchange before RANSAC is ONE all-gather of this block and
-    # RANSAC reads the gathered blocks through a pm_points_view (no concatenation pass).
-    # (N>1: the block is this rank's row of the gathered buffer and the record this rank's row of the gathered records,
-    # so both all-gathers run in place: no send-side copy)
-    g_blk = shard.gathered_blocks(world, nq, dev) if multi else None
-    d_blk, d_n, d_xy1, d_xy2 = shard.survivor_block(nq, dev, into=g_blk[rank] if multi else None)
-    d_key = torch.zeros(1, dtype=torch.int64, device=dev)
     n_all_max = nq * world
-    d_F = torch.zeros(9, dtype=torch.float64, device=dev)
-    d_mask = torch.zeros(n_all_max, dtype=torch.uint8, device=dev)
-    d_ninl = torch.zeros(1, dtype=torch.int32, device=dev)
-    d_ntot = torch.zeros(1, dtype=torch.int32, device=dev)
-    if multi:
-        g_rec = torch.zeros((world, 10), dtype=torch.float64, device=dev)
-        d_rec = g_rec[rank]                                                  # pm_ransac_record: key + F[9]
-        view = shard.view_of_blocks(g_blk, nq)
     hb, he = shard.hyp_shard(H, rank, world)
+
+    class Slot:
+        """Everything one in-flight image pair owns between the matcher and the end of RANSAC.  One contiguous
+        "survivor block" per rank: [count (int32) + 3 pad words | xy1: nq x 2 f32 | xy2: nq x 2 f32]; the filter writes
+        straight into it.  N > 1: the block is this rank's row of the gathered buffer and the record this rank's row of
+        the gathered records, so both all-gathers run in place (no send-side copy) and RANSAC reads the gathered blocks
+        through a pm_points_view (no concatenation pass)."""
+        def __init__(self):
+            self.knn = torch.empty((nq, K, 4), dtype=torch.int32, device=dev)
+            self.good = torch.empty((nq, 4), dtype=torch.int32, device=dev)
+            self.g_blk = shard.gathered_blocks(world, nq, dev) if multi else None
+            self.blk, self.n, self.xy1, self.xy2 = shard.survivor_block(nq, dev, into=self.g_blk[rank] if multi else None)
+            self.key = torch.zeros(1, dtype=torch.int64, device=dev)
+            self.F = torch.zeros(9, dtype=torch.float64, device=dev)
+            self.mask = torch.zeros(n_all_max, dtype=torch.uint8, device=dev)
+            self.ninl = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.ntot = torch.zeros(1, dtype=torch.int32, device=dev)
+            if multi:
+                self.g_rec = torch.zeros((world, 10), dtype=torch.float64, device=dev)
+                self.rec = self.g_rec[rank]                                  # pm_ransac_record: key + F[9]
+                self.view = shard.view_of_blocks(self.g_blk, nq)
+            self.ev_match = torch.cuda.Event()
+            self.ev_done = torch.cuda.Event()
+            self.used = False
+
+    slots = [Slot(), Slot()]
+    S0 = slots[0]
+    d_knn, d_good, d_n, d_xy1, d_xy2, d_key, d_F, d_mask, d_ninl, d_ntot = (S0.knn, S0.good, S0.n, S0.xy1, S0.xy2, S0.key, S0.F,
+                                                                            S0.mask, S0.ninl, S0.ntot)
+    g_blk = S0.g_blk
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
 
+    def match(c, S):
+        if hamming:
+            c.bf_knn_hamming_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, K, S.knn.data_ptr())
+            c.filter_ratio_gather_dev(S.knn.data_ptr(), nq, K, ratio, d_kp1.data_ptr(), d_kp2.data_ptr(),
+                                      S.good.data_ptr(), S.xy1.data_ptr(), S.xy2.data_ptr(), S.n.data_ptr())
+        else:       # 2-NN + ratio test + compaction + keypoint gather: one call (matcher launches, then the filter launch)
+            c.bf_knn_l2_ratio_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, knn_flags, ratio, d_kp1.data_ptr(),
+                                  d_kp2.data_ptr(), S.knn.data_ptr(), S.good.data_ptr(), S.xy1.data_ptr(), S.xy2.data_ptr(),
+                                  S.n.data_ptr())
+
+    def rest(c, S):
+        if multi:
+            dist.all_gather_into_tensor(S.g_blk.view(-1), S.blk)             # exchange 1: survivor blocks
+            c.ransac_shard_parts_dev(S.view, hb, he, thresh, seed, S.rec.data_ptr())
+            dist.all_gather_into_tensor(S.g_rec.view(-1), S.rec)             # exchange 2: 80-byte (key, F) records
+            c.ransac_finish_parts_dev(S.view, thresh, S.g_rec.data_ptr(), world, S.key.data_ptr(), S.F.data_ptr(),
+                                      S.mask.data_ptr(), n_all_max, S.ninl.data_ptr(), S.ntot.data_ptr())
+        else:
+            c.ransac_run_dev(S.xy1.data_ptr(), S.xy2.data_ptr(), nq, S.n.data_ptr(), hb, he, thresh, seed,
+                             S.key.data_ptr(), S.F.data_ptr(), S.mask.data_ptr(), S.ninl.data_ptr())
+
     def step(e=None):
+        """One pair, strictly serial on one stream (the form the stage brackets are taken on)."""
         if e:
             e[0].record(stream)
-        if hamming:
-            ctx.bf_knn_hamming_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, K, d_knn.data_ptr())
-            ctx.filter_ratio_gather_dev(d_knn.data_ptr(), nq, K, ratio, d_kp1.data_ptr(), d_kp2.data_ptr(),
-                                        d_good.data_ptr(), d_xy1.data_ptr(), d_xy2.data_ptr(), d_n.data_ptr())
-        else:       # 2-NN + ratio test + compaction + keypoint gather: one call, the filter rides the refinement launch
-            ctx.bf_knn_l2_ratio_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, knn_flags, ratio, d_kp1.data_ptr(),
-                                    d_kp2.data_ptr(), d_knn.data_ptr(), d_good.data_ptr(), d_xy1.data_ptr(), d_xy2.data_ptr(),
-                                    d_n.data_ptr())
+        match(ctx, S0)
         if e:
             e[1].record(stream)
-        if multi:
-            dist.all_gather_into_tensor(g_blk.view(-1), d_blk)             # exchange 1: survivor blocks
-            ctx.ransac_shard_parts_dev(view, hb, he, thresh, seed, d_rec.data_ptr())
-            dist.all_gather_into_tensor(g_rec.view(-1), d_rec)             # exchange 2: 80-byte (key, F) records
-            ctx.ransac_finish_parts_dev(view, thresh, g_rec.data_ptr(), world, d_key.data_ptr(), d_F.data_ptr(),
-                                        d_mask.data_ptr(), n_all_max, d_ninl.data_ptr(), d_ntot.data_ptr())
-        else:
-            ctx.ransac_run_dev(d_xy1.data_ptr(), d_xy2.data_ptr(), nq, d_n.data_ptr(), hb, he, thresh, seed,
-                               d_key.data_ptr(), d_F.data_ptr(), d_mask.data_ptr(), d_ninl.data_ptr())
+        rest(ctx, S0)
         if e:
             e[2].record(stream)
+
+    def step_pipe(i):
+        """Pair i of a pipelined run: its matcher on `stream`, its exchanges + RANSAC on a second stream; pair i+1's matcher
+        is enqueued behind this one's on `stream` and runs while this pair is in its collectives.  Two slots; a slot is
+        re-used only after the pair that held it has finished (ev_done).  (Three pairs in flight over three streams measured
+        SLOWER from this Python harness — 83.7 against 72.6 us per step at world 1: every torch.distributed call costs the
+        host ~20 us, so the deeper pipeline is host-bound; the C ABI's pm_mgpu_submit_dev has a host thread per device.)"""
+        S = slots[i & 1]
+        sb, cb = stream_b[0], ctx_b[0]
+        if S.used:
+            stream.wait_event(S.ev_done)
+        match(ctx, S)
+        S.ev_match.record(stream)
+        with torch.cuda.stream(sb):
+            sb.wait_event(S.ev_match)
+            rest(cb, S)
+            S.ev_done.record(sb)
+        S.used = True
 
     def fence():
         if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # The contract-timed region: exactly K steps, nothing but the path's own launches on the stream.  (Event records
+    def timed(fn, n):
+        fence()
+        t0 = time.perf_counter()
+        for i in range(n):
+            fn(i)
+        fence()
+        return time.perf_counter() - t0
+
+    # The contract-timed region: exactly K steps, nothing but the path's own launches on the stream(s).  (Event records
     # between the stages are not free on this hardware — each is a barrier packet that ends the overlap of one kernel's
-    # launch with its predecessor's tail; three per step cost ~14 us of a 65 us step — so the stage split is taken in
-    # a second pass of the same K steps, and `value`, the matcher stage's rate, comes from that instrumented pass:
-    # the conservative one of the two.)
-    for _ in range(args.warmup):
+    # launch with its predecessor's tail — so the stage split is taken in a second, serial pass of the same K steps, and
+    # `value`, the matcher stage's rate, comes from that instrumented pass: the conservative one.)
+    for i in range(args.warmup):
         step()
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step()
-    fence()
-    t1 = time.perf_counter()
-    wall = t1 - t0
+        step_pipe(i)
+    wall_serial = timed(lambda i: step(), args.steps)
+    wall_pipe = timed(step_pipe, args.steps)
     for i in range(args.steps):
         step(ev[i])
     fence()
     match_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     rest_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
     if multi:
-        tt = torch.tensor([wall, match_ms, rest_ms], dtype=torch.float64, device=dev)
+        tt = torch.tensor([wall_serial, wall_pipe, match_ms, rest_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall, match_ms, rest_ms = [float(x) for x in tt.tolist()]
+        wall_serial, wall_pipe, match_ms, rest_ms = [float(x) for x in tt.tolist()]
+    wall = wall_pipe if pipelined else wall_serial
     ms_per_step = wall / args.steps * 1e3
+
+    # ---- every collective by itself (SURVEY.md 8d): back-to-back all-gathers of the step's own buffers between two events
+    collectives = None
+    if multi:
+        def coll_us(fn, reps=100):
+            for _ in range(5):
+                fn()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            fence()
+            a.record(stream)
+            for _ in range(reps):
+                fn()
+            b.record(stream)
+            fence()
+            us = a.elapsed_time(b) / reps * 1e3
+            tt = torch.tensor([us], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+        collectives = {"allgather_survivor_blocks_us": coll_us(lambda: dist.all_gather_into_tensor(S0.g_blk.view(-1), S0.blk)),
+                       "survivor_block_bytes_per_rank": int(S0.blk.numel() * 4),
+                       "allgather_records_us": coll_us(lambda: dist.all_gather_into_tensor(S0.g_rec.view(-1), S0.rec)),
+                       "record_bytes_per_rank": 80, "ranks": world, "backend": args.backend,
+                       "note": "microseconds per collective, issued back to back on the step's stream (max over ranks)"}
+        step()                                       # leave slot 0 in the state of a whole step
+        fence()
 
     n_m = int((d_ntot if multi else d_n).item())
     key = int(d_key.item())
     n_inl = int(d_ninl.item())
+    both = all(int(S.key.item()) == key and int(S.ninl.item()) == n_inl for S in slots if S.used)   # every slot saw the same pair
 
-    # ---- sustained leg: the K timed steps above last a millisecond or two, during which the chip still holds its
+    # ---- sustained leg: the K timed steps above last a few milliseconds, during which the chip still holds its
     # boost clock; >= --sustain-seconds of back-to-back steps show the figure it sustains (DVFS give-back)
     sustained = None
     if args.sustain_seconds > 0:
         n_sus = max(args.steps, int(args.sustain_seconds / max(ms_per_step * 1e-3, 1e-6)) + 1)
-        es = []                                      # stage split measured on the last K steps of the run
+        t_sus = timed(step_pipe if pipelined else (lambda i: step()), n_sus)
+        es = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+        for e in es:                                 # stage split right behind the sustained run (clocks still settled)
+            step(e)
         fence()
-        t0 = time.perf_counter()
-        for i in range(n_sus):
-            if i >= n_sus - args.steps:
-                es.append([torch.cuda.Event(enable_timing=True) for _ in range(3)])
-                step(es[-1])
-            else:
-                step()
-        fence()
-        t_sus = time.perf_counter() - t0
         m_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in es]))
         if multi:
             tt = torch.tensor([t_sus, m_ms], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             t_sus, m_ms = [float(x) for x in tt.tolist()]
         sustained = {"seconds": t_sus, "steps": n_sus, "ms_per_step": t_sus / n_sus * 1e3, "match_ms": m_ms,
-                     "value": float(nq_total) * nt / (m_ms * 1e-3)}
+                     "value": float(nq_total) * nt / (m_ms * 1e-3), "pipelined": pipelined}
 
     # ---- per-kernel durations: instrumented replay of the same K steps (hipEvents on the stream
     # the kernels run on, recorded inside the library around each launch)
@@ -468,6 +548,74 @@ def main():
         step()
         fence()
 
+    # ---- the same SIFT data with NO hint (automatic route: the device finds the data integer-valued and takes the f16 pass;
+    # two more near-empty launches than the hinted call) — `value_auto_route`
+    auto_route = None
+    if not hamming and args.kind == "sift" and knn_flags and not args.headline_only:
+        a_n = torch.zeros(1, dtype=torch.int32, device=dev)
+
+        def astep():
+            ctx.bf_knn_l2_ratio_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, 0, ratio, d_kp1.data_ptr(), d_kp2.data_ptr(),
+                                    d_knn.data_ptr(), d_good.data_ptr(), d_xy1.data_ptr(), d_xy2.data_ptr(), a_n.data_ptr())
+        for _ in range(args.warmup):
+            astep()
+        fence()
+        ae = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ae[0].record(stream)
+        for _ in range(args.steps):
+            astep()
+        ae[1].record(stream)
+        fence()
+        a_ms = ae[0].elapsed_time(ae[1]) / args.steps
+        if multi:
+            tt = torch.tensor([a_ms], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            a_ms = float(tt.item())
+        auto_route = {"value": float(nq_total) * nt / (a_ms * 1e-3), "match_ms": a_ms, "matches": int(a_n.item()),
+                      "note": "same data, flags = 0: prep16 + prep16g (returns at once) + f16 pass + refinement + filter"}
+        step()
+        fence()
+
+    # ---- the matcher at 32k x 32k SIFT-128 (the size of BASELINE config 4's matrices, on the L2 path): the coarse kernel's
+    # roofline where launch and prologue no longer dominate
+    large = None
+    if not hamming and args.kind == "sift" and world == 1 and not args.no_large and not args.headline_only and args.workload in ("c2", "c3"):
+        nL = 32768
+        wl = synth.sift_like(nL, nL, dim, seed=0x32)
+        l_q, l_t = torch.from_numpy(wl[0]).to(dev), torch.from_numpy(wl[1]).to(dev)
+        l_out = torch.empty((nL, K, 4), dtype=torch.int32, device=dev)
+        for _ in range(3):
+            ctx.bf_knn_l2_dev(l_q.data_ptr(), nL, l_t.data_ptr(), nL, dim, K, l_out.data_ptr(), knn_flags)
+        fence()
+        le = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        reps = 20
+        le[0].record(stream)
+        for _ in range(reps):
+            ctx.bf_knn_l2_dev(l_q.data_ptr(), nL, l_t.data_ptr(), nL, dim, K, l_out.data_ptr(), knn_flags)
+        le[1].record(stream)
+        fence()
+        call_us = le[0].elapsed_time(le[1]) / reps * 1e3
+        ctx.timing_enable(True)
+        ctx.timing_reset()
+        for _ in range(reps):
+            ctx.bf_knn_l2_dev(l_q.data_ptr(), nL, l_t.data_ptr(), nL, dim, K, l_out.data_ptr(), knn_flags)
+        fence()
+        lk = {n: round(ctx.timing_get(n)[0] * 1e3, 2) for n in ("knn_l2_prep", "knn_l2_mfma_u8", "knn_l2_mfma_f16", "knn_l2_mfma_f16s", "knn_l2_refine")
+              if ctx.timing_get(n)[1]}
+        ctx.timing_enable(False)
+        got = l_out[5000:5128].cpu().numpy().view(pm.MATCH_DTYPE).reshape(128, K)
+        large = {"nq": nL, "nt": nL, "call_us": call_us, "kernels_us": lk, "rows_checked": None}
+        if not args.no_verify:
+            from oracle import pm_oracle as O
+            want = O.bf_knn_l2(wl[0][5000:5128], wl[1], K, nthreads=8)
+            large["rows_checked"] = 128
+            large["parity"] = "ok" if ((got["trainIdx"] == want["trainIdx"]).all() and
+                                       (got["distance"].view(np.uint32) == want["distance"].view(np.uint32)).all()) else "MISMATCH"
+        del l_q, l_t, l_out
+        ctx.bf_knn_l2_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, K, d_knn.data_ptr(), knn_flags)
+        step()
+        fence()
+
     # ---- parity spot check against the CPU oracle (untimed; checker only)
     parity = "skipped"
     if not args.no_verify and rank == 0:
@@ -506,7 +654,10 @@ def main():
         "vs_baseline": None,
         "dtype": "u8" if hamming else "f32",
         "dtype_note": "u8 bit strings; coarse pass i8xi8->i32 MFMA on +-1 expanded bits (exact), refinement u32 xor/popcount"
-                      if hamming else ("f32 in/out; coarse pass f16xf16->f32 MFMA (exact for u8-valued data), refinement f32"
+                      if hamming else ("f32 in/out; coarse pass i8 x i8 -> i32 MFMA on x - 128 (exact for u8-valued data), integer "
+                                       "refinement on the same byte copies, distances = canonical f32 bits"
+                                       if knn_flags == pm.api.PM_KNN_HINT_U8 else
+                                       "f32 in/out; coarse pass f16xf16->f32 MFMA (exact for u8-valued data), refinement f32"
                                        if knn_flags else "f32 in/out; coarse pass on f32-input MFMA (or the exact f16 one when the "
                                                          "device finds the data integer-valued), refinement f32"),
         "data": "synthetic",
@@ -518,6 +669,9 @@ def main():
                    "coarse_route": "n/a (Hamming)" if hamming else
                                    {pm.api.PM_KNN_HINT_U8: "i8-MFMA on x - 128 (u8 hint, device-verified)",
                                     pm.api.PM_KNN_HINT_INTEGER: "f16-MFMA (integer hint, device-verified)"}.get(knn_flags, "auto")},
+        "ms_per_step_serial": wall_serial / args.steps * 1e3, "ms_per_step_pipelined": wall_pipe / args.steps * 1e3,
+        "step_form": ("pipelined: pair i+1's matcher on a second stream while pair i is in its exchanges / RANSAC" if pipelined
+                      else "serial: one pair after the other on one stream"),
         "stage_ms": {"match": match_ms, "ransac_and_exchange": rest_ms,
                      "note": "hipEvent brackets in a second pass of the same K steps (the events themselves add "
                              "~4-5 us per bracket); ms_per_step is the un-instrumented pass"},
@@ -525,6 +679,10 @@ def main():
                    "best_hyp": pm.api.ransac_key_hyp(key) if key else None},
         "kernels_us": kern, "knn_refine": kstats, "parity": parity,
     }
+    if collectives:
+        out["collectives"] = collectives
+    if not both:
+        out["parity"] = "MISMATCH (the pipeline slots disagree)"
     if general:
         out["value_general_floats"] = general["value"]
         out["general_floats"] = general
@@ -587,9 +745,25 @@ def main():
                            "algorithmic_bytes": (nq + nt) * dim * 4 + nq * K * 16,
                            "dtype": "f32-input MFMA (v_mfma_f32_32x32x2_f32)"}
     if out.get("roofline", {}).get("traffic") is not None:
-        out["roofline"]["traffic_source"] = "profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this kernel " \
+        out["roofline"]["traffic_source"] = "profiles/r03_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this kernel " \
                                             "on this workload, separate passes, gfx950 correction), stamped with the hash of " \
                                             "the kernel sources it was measured on: " + _kernel_source_sha()
+    if auto_route:
+        out["value_auto_route"] = auto_route["value"]
+        out["auto_route"] = auto_route
+    if large:
+        lflops = 2.0 * dim * large["nq"] * large["nt"]
+        for kn, peak, unit in (("knn_l2_mfma_u8", 2 * PEAK_F16_MFMA_TFLOPS, "TOP/s"), ("knn_l2_mfma_f16", PEAK_F16_MFMA_TFLOPS, "TFLOP/s"),
+                               ("knn_l2_mfma_f16s", PEAK_F16_MFMA_TFLOPS, "TFLOP/s")):
+            if kn in large["kernels_us"]:
+                ach = lflops / (large["kernels_us"][kn] * 1e-6) / 1e12
+                out["roofline_large"] = {"kernel": kn, "workload": "32768 x 32768 SIFT-128 f32, BF-L2 2-NN (matcher call only)",
+                                         "bound": "mfma", "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+                                         "frac_of_f16_peak": ach / PEAK_F16_MFMA_TFLOPS,
+                                         "kernel_us": large["kernels_us"][kn], "call_us": large["call_us"],
+                                         "kernels_us": large["kernels_us"], "pairs_per_s": float(large["nq"]) * large["nt"] / (large["call_us"] * 1e-6),
+                                         "parity": large.get("parity", "skipped"), "traffic": pmc_traffic("l32k:" + kn, large["nq"], large["nt"])}
+                break
     if f32_route_us > 0:
         ach = flops / (f32_route_us * 1e-6) / 1e12
         out["roofline_f32_route"] = {"kernel": "knn_l2_mfma", "bound": "mfma", "achieved": ach,

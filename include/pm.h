@@ -82,6 +82,10 @@ int  pm_ctx_knn_stats(pm_ctx* ctx, int* rescans, int* nonfinite);
  * 1 = f16 matrix pass on rounded copies of general floats, 2 = f32-input matrix pass, 3 = i8 matrix pass on centred
  * u8-valued copies (synchronises). */
 int  pm_ctx_knn_route(pm_ctx* ctx, int* route);
+/* pm_bf_knn_l2_ratio_dev in its fused form (no record buffer / PM_OPT_FILTER_FUSION = 2) compacts with bounded look-back
+ * polls.  *gave_up != 0: a poll of the LAST such call on this context ran out — that call's survivors and count are not to
+ * be used (never observed on hardware; the two-launch form has an always-correct fallback instead).  Synchronises. */
+int  pm_ctx_filter_fusion_status(pm_ctx* ctx, int* gave_up);
 /* Explicit per-context switches for tests and A/B timing (the library reads no environment variables).
  * Every option defaults to 0 = automatic; a value outside an option's range is PM_E_INVALID. */
 enum {
@@ -396,8 +400,9 @@ int pm_host_register(void* ptr, size_t bytes);
 int pm_host_unregister(void* ptr);
 
 /* ---- the path over the GPUs of one node (SURVEY.md 8b `pm_ransac_reduce`, 8e) ----------------------------
- * One host thread, one context per device, one RCCL communicator set (ncclCommInitAll over xGMI); RCCL is bound
- * at run time, so single-GPU users never load it.  `devices`: HIP ordinals (NULL: 0 .. n_dev-1).
+ * One context per (device, lane), one RCCL communicator set per lane (ncclCommInitAll over xGMI), ONE HOST THREAD PER
+ * DEVICE that enqueues that device's launches and collectives; RCCL is bound at run time, so single-GPU users never
+ * load it.  `devices`: HIP ordinals (NULL: 0 .. n_dev-1).
  *   pm_mgpu_ransac_fundamental  main.cpp:95-98 with the hypothesis ids cut into n_dev contiguous ranges over
  *       replicated correspondences; the exchange is ONE all-gather of the 80-byte pm_ransac_record per device
  *       (arg-max all-reduce with its payload); every device finishes from the winning record, device 0's answer
@@ -407,18 +412,45 @@ int pm_host_unregister(void* ptr);
  *       as above over the gathered view, all-gather #2 of the records.  desc1/desc2: n x dim float32 rows
  *       (binary == 0, L2, knn_flags as pm_bf_knn_l2_f32) or n x dim bytes (binary != 0, Hamming).  Outputs: `good`
  *       (n1 records, first *n_good valid, query order, queryIdx = row of desc1), F, mask (per good match), counts.
- *       PM_E_TOO_FEW / PM_E_NO_MODEL as pm_ransac_fundamental (good / *n_good are valid either way). */
+ *       PM_E_TOO_FEW / PM_E_NO_MODEL as pm_ransac_fundamental (good / *n_good are valid either way).  Host inputs go
+ *       through ONE pinned staging copy that all devices' copy engines read concurrently.
+ * Streamed form (round 3) — what a caller with many image pairs against one train image uses:
+ *   pm_mgpu_set_lanes           1 .. 4 lanes per device (stream + communicator + buffers each); pair j runs on lane
+ *                               j mod L, so pair j+1's matcher overlaps pair j's two all-gathers.  Default 1.
+ *   pm_mgpu_set_train[_dev]     the replicated train side (main.cpp:36-40, image 2) made RESIDENT on every device: uploaded
+ *                               once from host memory, or adopted from per-device device pointers the caller keeps alive.
+ *   pm_mgpu_submit_dev          one image pair from DEVICE pointers: d_desc1[g] / d_kp1_xy[g] = device g's block of
+ *                               rows[g] query rows (blocks in device order = query order; equal blocks, the last possibly
+ *                               short, when match records with global queryIdx are wanted).  Returns at once with a ticket.
+ *                               A lane holds one pair's results until they are collected: at most `lanes` pairs are in flight.
+ *   pm_mgpu_collect             blocks for one ticket (any order): result as pm_pair_result (status
+ *                               PM_OK / PM_E_TOO_FEW / PM_E_NO_MODEL), optional match records (sum of rows) and mask.
+ *   pm_mgpu_allgather_latency   the collective by itself: microseconds per all-gather of bytes_per_device.
+ *   pm_mgpu_batch_run           BASELINE config C5 behind the ABI: pm_batch_run with pair p on device p mod n_dev, one host
+ *                               thread per device, results in job order (arguments as pm_batch_create + pm_batch_run). */
 typedef struct pm_mgpu pm_mgpu;   /* opaque */
 int pm_mgpu_create(int n_dev, const int* devices, pm_mgpu** out);
 int pm_mgpu_destroy(pm_mgpu* mg);
 int pm_mgpu_size(const pm_mgpu* mg);
-pm_ctx* pm_mgpu_ctx(pm_mgpu* mg, int i);        /* device i's context (options, timing); owned by mg */
+pm_ctx* pm_mgpu_ctx(pm_mgpu* mg, int i);        /* device i's lane-0 context (options, timing); owned by mg */
+pm_ctx* pm_mgpu_lane_ctx(pm_mgpu* mg, int i, int lane);
 int pm_mgpu_ransac_fundamental(pm_mgpu* mg, const float* xy1, const float* xy2, int n, const pm_ransac_params* p,
                                double F[9], uint8_t* mask, int* n_inliers, uint64_t* best_key);
 int pm_mgpu_match_ransac(pm_mgpu* mg, const void* desc1, int n1, const void* desc2, int n2, int dim, int binary,
                          const float* kp1_xy, const float* kp2_xy, float ratio, int knn_flags,
                          const pm_ransac_params* p, pm_match* good, int* n_good, double F[9], uint8_t* mask,
                          int* n_inliers, uint64_t* best_key);
+int pm_mgpu_set_lanes(pm_mgpu* mg, int n_lanes);
+int pm_mgpu_set_train(pm_mgpu* mg, const void* desc2, int n2, int dim, int binary, const float* kp2_xy);
+int pm_mgpu_set_train_dev(pm_mgpu* mg, const void* const* d_desc2, int n2, int dim, int binary, const float* const* d_kp2_xy);
+int pm_mgpu_submit_dev(pm_mgpu* mg, const void* const* d_desc1, const int32_t* rows, const float* const* d_kp1_xy,
+                       float ratio, int knn_flags, const pm_ransac_params* p, int* ticket);
+int pm_mgpu_collect(pm_mgpu* mg, int ticket, pm_pair_result* result, pm_match* good, uint8_t* mask);
+int pm_mgpu_allgather_latency(pm_mgpu* mg, int bytes_per_device, int reps, double* us_per_collective);
+int pm_mgpu_batch_run(pm_mgpu* mg, int n_lanes, int max_n1, int max_n2, int dim, const pm_pair_job* jobs, int n_jobs,
+                      float ratio, int knn_flags, const pm_ransac_params* p, pm_pair_result* results, pm_match* good,
+                      uint8_t* masks);
+int pm_mgpu_batch_set_option(pm_mgpu* mg, int option, int value);   /* pm_ctx_set_option on every context of mg */
 
 /* ---- residual report (main.cpp:103-123) -----------------------------------------------------
  * r[i] = [xa ya 1] * F * [xb yb 1]^T in fp64.  transposed != 0 reproduces the reference

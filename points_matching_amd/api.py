@@ -28,6 +28,7 @@ PM_OK, PM_E_INVALID, PM_E_TOO_FEW, PM_E_NO_MODEL, PM_E_HIP, PM_E_NOMEM, PM_E_UNS
 EXPORTS = [
     "pm_ctx_create", "pm_ctx_destroy", "pm_ctx_set_stream", "pm_ctx_synchronize",
     "pm_ctx_timing_enable", "pm_ctx_timing_reset", "pm_ctx_timing_get", "pm_ctx_knn_diag_enable", "pm_ctx_knn_stats", "pm_ctx_knn_route",
+    "pm_ctx_filter_fusion_status",
     "pm_last_error",
     "pm_status_string", "pm_version",
     "pm_bf_knn_l2_f32", "pm_bf_knn_l2_f32_dev", "pm_bf_knn_hamming_u8", "pm_bf_knn_hamming_u8_dev",
@@ -39,6 +40,8 @@ EXPORTS = [
     "pm_ctx_set_option", "pm_ctx_get_option", "pm_bf_knn_l2_ratio_dev",
     "pm_flann_build", "pm_flann_destroy", "pm_flann_knn_l2_f32", "pm_flann_knn_l2_f32_dev", "pm_flann_export",
     "pm_mgpu_create", "pm_mgpu_destroy", "pm_mgpu_size", "pm_mgpu_ctx", "pm_mgpu_ransac_fundamental", "pm_mgpu_match_ransac",
+    "pm_mgpu_lane_ctx", "pm_mgpu_set_lanes", "pm_mgpu_set_train", "pm_mgpu_set_train_dev", "pm_mgpu_submit_dev", "pm_mgpu_collect",
+    "pm_mgpu_allgather_latency", "pm_mgpu_batch_run", "pm_mgpu_batch_set_option",
     "pm_batch_create", "pm_batch_destroy", "pm_batch_run", "pm_batch_set_option", "pm_host_register", "pm_host_unregister",
     "pm_lmeds_fundamental", "pm_lmeds_fundamental_dev", "pm_lmeds_default_iters", "pm_ransac7_adaptive",
     "pm_epipolar_residuals", "pm_f_scale_f33", "pm_epilines", "pm_epiline_endpoints",
@@ -263,6 +266,11 @@ class Context:
 
     def knn_diag_enable(self, on=True):
         _check(lib().pm_ctx_knn_diag_enable(self._h, int(on)))
+
+    def filter_fusion_gave_up(self):
+        g = C.c_int()
+        _check(lib().pm_ctx_filter_fusion_status(self._h, C.byref(g)))
+        return g.value
 
     def knn_stats(self):
         r, nf = C.c_int(), C.c_int()
@@ -552,6 +560,62 @@ class MultiGpu:
         if rc not in (PM_OK, PM_E_NO_MODEL, PM_E_TOO_FEW):
             _check(rc)
         return rc, good[:ngood.value].copy(), F.reshape(3, 3), mask[:ngood.value].copy(), ninl.value, key.value
+
+
+    # ---- streamed form: resident train side, device pointers in, tickets out -------------------------------------
+    def set_lanes(self, n_lanes):
+        _check(lib().pm_mgpu_set_lanes(self._h, n_lanes))
+
+    def set_option(self, option, value):
+        _check(lib().pm_mgpu_batch_set_option(self._h, option, value))
+
+    def set_train(self, desc2, kp2):
+        binary = desc2.dtype == np.uint8
+        desc2 = np.ascontiguousarray(desc2, np.uint8 if binary else np.float32)
+        kp2 = np.ascontiguousarray(kp2, np.float32).reshape(-1, 2)
+        _check(lib().pm_mgpu_set_train(self._h, _p(desc2), desc2.shape[0], desc2.shape[1], int(binary), _p(kp2)))
+
+    def set_train_dev(self, desc2_ptrs, n2, dim, binary, kp2_ptrs):
+        """per-device device pointers (the caller keeps the buffers alive)"""
+        a = (C.c_void_p * self.n)(*desc2_ptrs)
+        b = (C.c_void_p * self.n)(*kp2_ptrs)
+        _check(lib().pm_mgpu_set_train_dev(self._h, a, n2, dim, int(binary), b))
+
+    def submit_dev(self, desc1_ptrs, rows, kp1_ptrs, ratio, iters, thresh_px, seed, knn_flags=0, kind=PM_ERR_SAMPSON):
+        a = (C.c_void_p * self.n)(*desc1_ptrs)
+        b = (C.c_void_p * self.n)(*kp1_ptrs)
+        r = (C.c_int32 * self.n)(*rows)
+        prm = RansacParams(0, iters, seed, thresh_px, kind)
+        t = C.c_int()
+        _check(lib().pm_mgpu_submit_dev(self._h, a, r, b, C.c_float(ratio), knn_flags, C.byref(prm), C.byref(t)))
+        return t.value
+
+    def collect(self, ticket, n1=0, want_good=False, want_mask=False):
+        """Returns (PairResult, good records or None, mask or None); n1 = total query rows of the pair (buffer sizes)."""
+        res = PairResult()
+        good = np.zeros(max(n1, 1), MATCH_DTYPE) if want_good else None
+        mask = np.zeros(max(n1, 1), np.uint8) if want_mask else None
+        _check(lib().pm_mgpu_collect(self._h, ticket, C.byref(res), _p(good) if want_good else None, _p(mask) if want_mask else None))
+        ng = max(res.n_good, 0)
+        return res, (good[:ng].copy() if want_good else None), (mask[:ng].copy() if want_mask else None)
+
+    def allgather_latency(self, bytes_per_device, reps=200):
+        us = C.c_double()
+        _check(lib().pm_mgpu_allgather_latency(self._h, bytes_per_device, reps, C.byref(us)))
+        return us.value
+
+    def batch_run(self, jobs, n_lanes, max_n1, max_n2, dim, ratio, iters, thresh_px, seed, knn_flags=0, kind=PM_ERR_SAMPSON,
+                  want_good=False, want_masks=False):
+        """BASELINE config C5 over the devices (pair p -> device p mod n): like PairBatch.run."""
+        arr = jobs if isinstance(jobs, C.Array) else PairBatch.make_jobs(jobs)
+        n = len(arr)
+        res = (PairResult * n)()
+        good = np.zeros((n, max_n1), MATCH_DTYPE) if want_good else None
+        masks = np.zeros((n, max_n1), np.uint8) if want_masks else None
+        prm = RansacParams(0, iters, seed, thresh_px, kind)
+        _check(lib().pm_mgpu_batch_run(self._h, n_lanes, max_n1, max_n2, dim, arr, n, C.c_float(ratio), knn_flags, C.byref(prm), res,
+                                       _p(good) if want_good else None, _p(masks) if want_masks else None))
+        return res, good, masks
 
 
 # ---- FlannBasedMatcher-compatible approximate matcher (main.cpp:44; SPEC S17) ---------------------------

@@ -19,7 +19,7 @@ LIB = os.path.join(HERE, "libpm_hip.so")
 SOURCES = ["pm_capi.cpp", "knn_l2.hip", "knn_coarse.hip", "knn_hamming.hip", "ransac.hip", "ransac_fused.hip", "ransac_shard.hip", "filter_gather.hip",
            "pair_batch.cpp", "lmeds.hip", "mgpu.cpp", "flann.hip"]
 # per-file extra flags: the coarse kernels only nominate candidates (no result bit depends on them)
-EXTRA = {"knn_coarse.hip": ["-ffinite-math-only"]}
+EXTRA = {"knn_coarse.hip": ["-ffinite-math-only"], "mgpu.cpp": ["-pthread"]}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function",
@@ -63,7 +63,7 @@ def build(force=False, verbose=False, extra_flags=()):
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     if force or jobs or not os.path.exists(LIB):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-pthread"])
     return LIB
 
 

@@ -594,7 +594,7 @@ struct KnnFuse {
     unsigned long long* pk;       // [nq] (distance bits << 32) | trainIdx of the nearest neighbour
     unsigned long long* tile;     // [tiles] arrival word: arrivals << 32 | 32 keep bits; back to 0 when the tile is taken
     unsigned* tilecnt;            // [tiles] epoch << 8 | survivors (epoch-tagged, never cleared)
-    unsigned* err;                // set to the epoch if a look-back gave up (never observed; reported by pm_ctx_knn_stats)
+    unsigned* err;                // set to the epoch if a look-back gave up (never observed; read by pm_ctx_filter_fusion_status)
     unsigned epoch;
 };
 constexpr int KF_TILE_BLOCKS = 8;                 // workgroups (of 4 queries) per tile

@@ -249,6 +249,19 @@ int pm_ctx_knn_diag_enable(pm_ctx* ctx, int enable)
     return PM_OK;
 }
 
+// The compaction that rides the refinement launch (pm_bf_knn_l2_ratio_dev without a record buffer) bounds its look-back
+// polls; a poll that ran out stores the call's epoch at byte 48 of the side-band block.  *gave_up != 0: the LAST such call
+// on this context placed survivors with an incomplete prefix — its outputs must not be used (never observed).
+int pm_ctx_filter_fusion_status(pm_ctx* ctx, int* gave_up)
+{
+    PM_REQUIRE(ctx != nullptr && gave_up != nullptr, PM_E_INVALID, "null argument");
+    unsigned w = 0;
+    PM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    PM_HIP_CHECK(hipMemcpy(&w, reinterpret_cast<const char*>(ctx->knn_stats) + 48, sizeof w, hipMemcpyDeviceToHost));
+    *gave_up = (ctx->kf_epoch != 0u && w == ctx->kf_epoch) ? 1 : 0;
+    return PM_OK;
+}
+
 int pm_ctx_knn_stats(pm_ctx* ctx, int* rescans, int* nonfinite)
 {
     PM_REQUIRE(ctx != nullptr, PM_E_INVALID, "ctx is null");

@@ -488,6 +488,8 @@ int fused_launch_t(pm_ctx* ctx, const pm_points_view& v, const pm_ransac_params*
     const long long nh = p->hyp_end - p->hyp_begin;
     const long long cap_total = static_cast<long long>(v.parts) * v.cap;
     PM_REQUIRE(nh >= 1, PM_E_INVALID, "fused_launch: empty hypothesis range");
+    // the kernel counts the ids of a launch in an int: one shard holds at most 2^31 - 1 of them (ids themselves go to 2^32)
+    PM_REQUIRE(nh <= 0x7FFFFFFFLL, PM_E_INVALID, "a single launch takes at most 2^31 - 1 hypothesis ids: split the range");
     const int hb = fused_hb(ctx, nh);
     const int nwg = static_cast<int>((nh + hb - 1) / hb);
     RfSlot* slots = static_cast<RfSlot*>(pm::arena_take(ctx, sizeof(RfSlot) * static_cast<size_t>(nwg)));

@@ -12,6 +12,10 @@
 //          [--print-epilines] [--epilines out.ppm [--canvas W H] [--img2 right.pgm]] [--matcher bf|flann]
 // --matcher flann: the reference's ACTIVE matcher object (`FlannBasedMatcher matcher;`, main.cpp:44): 4 randomised
 // kd-trees, 32 checks (pm_flann_*; approximate, seeded by --seed); bf (default) is the exact matcher of main.cpp:43.
+// NOTE: the default matcher DEVIATES from main.cpp:44 on purpose — the exact matcher is faster on this hardware at every
+// size and reproducible (FLANN seeds its trees from C rand()); `--matcher flann` gives the reference's literal flow
+// (FLANN 1-NN -> midpoint filter -> 7-point LMedS).  The image front end (--img1/--img2) is a SIFT-style detector, not
+// the reference's SURF(8000) (main.cpp:22-40): no compatibility with OpenCV's keypoints is claimed.
 // --gpus N (> 1): matcher rows and hypothesis ids are sharded over N GPUs through pm_mgpu_match_ransac (RCCL behind
 // the C ABI); needs --filter ratio --method ransac8 (the sharded form of the path, BASELINE config C4).
 // --print-epilines / --epilines: main.cpp:127-142 — the epipolar lines of the image-1 points in image 2
@@ -229,7 +233,8 @@ int main(int argc, char** argv)
     if (desc1.empty() || desc2.empty() || kp1.empty() || kp2.empty()) {
         fprintf(stderr, "usage: pm_cli (--img1 L.pgm --img2 R.pgm | --desc1 A --desc2 B --kp1 KA --kp2 KB) [--filter midpoint|ratio] "
                         "[--ratio r] [--method 7point-lmeds|ransac8] [--iters n] [--thresh px] [--seed s] [--f-scale opencv|unit] "
-                        "[--matcher bf|flann] [--gpus N] [--print-epilines] [--epilines out.ppm] [--json] [--quiet]\n");
+                        "[--matcher bf|flann] [--gpus N] [--print-epilines] [--epilines out.ppm] [--json] [--quiet]\n"
+                        "  (default matcher bf = exact brute force, main.cpp:43; the reference's active one is --matcher flann, main.cpp:44)\n");
         return 2;
     }
     if (!load_matrix(desc1, d1) || !load_matrix(desc2, d2) || !load_matrix(kp1, k1) || !load_matrix(kp2, k2)) return 1;
@@ -257,7 +262,7 @@ int main(int argc, char** argv)
     using clk = std::chrono::steady_clock;
     pm_ctx* ctx = nullptr;
     pm_mgpu* mg = nullptr;
-    int rc = PM_OK;
+    int rc = PM_OK, est_rc = PM_OK;
     std::vector<pm_match> good(static_cast<size_t>(d1.rows) + 1);
     int n_good = 0, n_inl = 0;
     std::vector<float> xy1, xy2;
@@ -293,6 +298,7 @@ int main(int argc, char** argv)
         rc = pm_mgpu_match_ransac(mg, d1.data.data(), d1.rows, d2.data.data(), d2.rows, d1.cols, d1.dtype == 1, k1.f32(), k2.f32(),
                                   ratio, 0, &prm, good.data(), &n_good, F, mask.data(), &n_inl, &key);
         if (rc != PM_OK && rc != PM_E_TOO_FEW && rc != PM_E_NO_MODEL) return fail("pm_mgpu_match_ransac", rc);
+        est_rc = rc;
         t1 = t2 = t3 = clk::now();
         good.resize(n_good);
         const int r2 = gather_and_list();
@@ -354,6 +360,7 @@ int main(int argc, char** argv)
         rc = pm_ransac_fundamental(ctx, xy1.data(), xy2.data(), n_good, &prm, F, mask.data(), &n_inl, &key);
         if (rc != PM_OK && rc != PM_E_TOO_FEW && rc != PM_E_NO_MODEL) return fail("pm_ransac_fundamental", rc);
     }
+    est_rc = rc;                             // the estimator's own status (PM_E_TOO_FEW / PM_E_NO_MODEL are results, not failures)
     t3 = clk::now();
     }
     // like cv::findFundamentalMat, a failed estimate yields the zero matrix
@@ -393,7 +400,7 @@ int main(int argc, char** argv)
                "\"ms\": {\"match\": %.3f, \"filter_gather\": %.3f, \"ransac\": %.3f}, "
                "\"F\": [%.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g]}\n",
                d1.rows, d2.rows, d1.cols, n_good, n_inl,
-               method == "7point-lmeds" ? lmeds_model : static_cast<long long>(key ? pm_ransac_key_hyp(key) : 0u), rc == PM_OK ? 0 : rc,
+               method == "7point-lmeds" ? lmeds_model : static_cast<long long>(key ? pm_ransac_key_hyp(key) : 0u), est_rc,
                mean_abs, mean_fwd, ms(t0, t1), ms(t1, t2), ms(t2, t3), F[0], F[1], F[2], F[3], F[4], F[5], F[6],
                F[7], F[8]);
     }

@@ -30,6 +30,8 @@ def test_two_ranks_c3_shape(scaling):
     assert d["n_gpus"] == 2 and d["parity"] == "ok" and d["scaling"] == scaling
     assert d["ransac"]["n_matches"] > 300 and d["ransac"]["inliers"] > 100
     assert "ransac_fused" in d["kernels_us"] and "ransac_finish" in d["kernels_us"]
+    assert d["step_form"].startswith("pipelined") and d["ms_per_step"] == d["ms_per_step_pipelined"] and d["ms_per_step_serial"] > 0
+    assert d["collectives"]["ranks"] == 2 and d["collectives"]["allgather_records_us"] > 0
 
 
 def test_two_ranks_c4_strong_shape():

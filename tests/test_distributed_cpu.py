@@ -73,6 +73,78 @@ def test_gloo_sharded_path_equals_unsharded(world):
     assert res[0][7] == (world, 512, 4 + 4 * 512)
 
 
+def _pipe_worker(rank, world, port, q):
+    """Four image pairs through the TWO-SLOT pipeline bench.py runs for N > 1 (pair i in slot i % 2; pair i+1's matcher and
+    its survivor all-gather start before pair i's RANSAC half has finished; a slot is re-used only when its pair is done).
+    CPU analogue: the exchanges are asynchronous gloo collectives, the compute is the oracle."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import pm_oracle as O
+        from points_matching_amd import shard, synth
+        nq, nt, H, P = 256, 300, 200, 4
+        slots = []
+        for _ in range(2):
+            g_blk = shard.gathered_blocks(world, nq, "cpu")
+            blk, n, xy1, xy2 = shard.survivor_block(nq, "cpu", into=g_blk[rank])
+            slots.append({"g_blk": g_blk, "blk": blk, "n": n, "xy1": xy1, "xy2": xy2, "g_rec": torch.zeros((world, 10), dtype=torch.float64),
+                          "w1": None, "pair": None})
+        hb, he = shard.hyp_shard(H, rank, world)
+        results = {}
+
+        def match(i):
+            S = slots[i & 1]
+            assert S["pair"] is None                        # the slot's previous pair has finished
+            w = synth.pair_workload(nq, nt, 64, seed=100 + i, rank=rank, planted=0.5, kind="surf")
+            good = O.filter_ratio(O.bf_knn_l2(w["q"], w["t"], 2), 0.8)
+            S["n"][0] = good.size
+            S["xy1"][:good.size] = torch.from_numpy(O.gather_points(w["kp1"], good["queryIdx"]))
+            S["xy2"][:good.size] = torch.from_numpy(O.gather_points(w["kp2"], good["trainIdx"]))
+            S["w1"] = dist.all_gather_into_tensor(S["g_blk"].view(-1), S["blk"], async_op=True)   # exchange 1 in flight
+            S["pair"] = i
+
+        def rest(i):
+            S = slots[i & 1]
+            S["w1"].wait()
+            a1, a2, _ = shard.concat_blocks(S["g_blk"], nq)
+            rc, F_r, _, _, key_r = O.ransac_fundamental(a1, a2, he, 1.0, 77 + i, hyp_begin=hb)
+            rec = torch.from_numpy(shard.make_record(key_r, F_r))
+            dist.all_gather_into_tensor(S["g_rec"].view(-1), rec)                                   # exchange 2
+            key, F = shard.pick_record(S["g_rec"].numpy())
+            full = O.ransac_fundamental(a1, a2, H, 1.0, 77 + i)
+            results[i] = (key == full[4], bool((F.view(np.uint64) == full[1].view(np.uint64)).all()), a1.tobytes())
+            S["pair"] = None
+
+        for i in range(P):
+            match(i)                                         # pair i's matcher + exchange 1 ...
+            if i > 0:
+                rest(i - 1)                                  # ... overlap pair i-1's RANSAC half
+        rest(P - 1)
+        q.put((rank, [results[i][:2] for i in range(P)], [results[i][2] for i in range(P)]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_pipelined_pairs_equal_unsharded():
+    world = 2
+    port = 31000 + (os.getpid() * 11) % 2000
+    ctxmp = mp.get_context("spawn")
+    q = ctxmp.Queue()
+    procs = [ctxmp.Process(target=_pipe_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0, 'worker failed'
+    res = sorted(q.get(timeout=10) for _ in range(world))
+    for r in res:
+        assert all(k and f for k, f in r[1])                 # every pair: winner key and model bits = the unsharded run's
+    assert res[0][2] == res[1][2]                            # every pair: identical gathered correspondences on both ranks
+    assert len(set(res[0][2])) == 4                          # ... and the four pairs did not share a slot's contents
+
+
 def test_row_shard_partitions():
     from points_matching_amd import shard
     for n in (1, 7, 8192, 32768, 1001):

@@ -146,7 +146,7 @@ def test_fused_matcher_filter_equals_the_two_call_form(ctx, oracle, nq, nt, dim,
     import torch
     dev = torch.device("cuda", 0)
     w = synth.pair_workload(nq, nt, dim, seed=nq + nt, planted=0.4, kind=kind)
-    flags = pm.api.PM_KNN_HINT_INTEGER if kind == "sift" else 0
+    flags = (pm.api.PM_KNN_HINT_U8 if (nq + nt) % 2 else pm.api.PM_KNN_HINT_INTEGER) if kind == "sift" else 0
     d_q, d_t = torch.from_numpy(w["q"]).to(dev), torch.from_numpy(w["t"]).to(dev)
     d_kp1, d_kp2 = torch.from_numpy(w["kp1"]).to(dev), torch.from_numpy(w["kp2"]).to(dev)
     want = oracle.filter_ratio(oracle.bf_knn_l2(w["q"], w["t"], 2, nthreads=8), 0.8)
@@ -169,6 +169,7 @@ def test_fused_matcher_filter_equals_the_two_call_form(ctx, oracle, nq, nt, dim,
             ctx.set_option(pm.api.PM_OPT_FILTER_FUSION, 0)
         n = int(d_n.item())
         assert n == want.size, (mode, with_knn)
+        assert ctx.filter_fusion_gave_up() == 0             # no look-back poll of the fused compaction ran out
         got = d_good.cpu().numpy().view(pm.MATCH_DTYPE).reshape(-1)[:n]
         assert_matches_equal(got, want, "fused good list %s" % ((mode, with_knn),))
         assert (d_xy1.cpu().numpy()[:n] == w["kp1"][want["queryIdx"]]).all()
