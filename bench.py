@@ -79,18 +79,39 @@ def bench_c5(args, world, rank, local_rank, dev, multi, saved_stdout):
     n, dim, H, ratio, thresh, seed = 4096, 128, 2048, 0.8, 1.0, 0x5EED
     my_pairs = shard.pair_shard(args.pairs, rank, world)
     distinct = min(len(my_pairs), 16)          # distinct synthetic pairs held in pinned memory, cycled
-    hold = []
-    for i in range(distinct):
-        w = synth.pair_workload(n, n, dim, seed=0xC5 + my_pairs[i], kind="sift")
-        hold.append({k: torch.from_numpy(np.ascontiguousarray(w[k])).pin_memory() for k in ("q", "t", "kp1", "kp2")})
-    jobs = []
-    for i in range(len(my_pairs)):
-        h = hold[i % distinct]
-        jobs.append((h["q"].data_ptr(), n, h["t"].data_ptr(), n, h["kp1"].data_ptr(), h["kp2"].data_ptr()))
+    u8 = args.c5_desc == "u8"
+    ddt = np.uint8 if u8 else np.float32
+
+    def build_jobs(one_block):
+        """pinned host copies of the distinct pairs and the job list: four separate arrays per pair, or ONE block
+        desc1 | desc2 | kp1 | kp2 (256-byte aligned sections), which pm_batch_run sends in one copy"""
+        hold, jobs = [], []
+        for i in range(distinct):
+            w = synth.pair_workload(n, n, dim, seed=0xC5 + my_pairs[i], kind="sift")
+            parts = [np.ascontiguousarray(w["q"].astype(ddt)), np.ascontiguousarray(w["t"].astype(ddt)), w["kp1"], w["kp2"]]
+            if one_block:
+                offs, total = [], 0
+                for p in parts:
+                    total = (total + 255) // 256 * 256
+                    offs.append(total)
+                    total += p.nbytes
+                blk = torch.zeros(total, dtype=torch.uint8).pin_memory()
+                for p, o in zip(parts, offs):
+                    blk[o:o + p.nbytes] = torch.from_numpy(p.view(np.uint8).reshape(-1))
+                hold.append((blk, [blk.data_ptr() + o for o in offs]))
+            else:
+                ts = [torch.from_numpy(p).pin_memory() for p in parts]
+                hold.append((ts, [t.data_ptr() for t in ts]))
+        for i in range(len(my_pairs)):
+            a = hold[i % distinct][1]
+            jobs.append((a[0], n, a[1], n, a[2], a[3]))
+        return hold, jobs
+    hold, jobs = build_jobs(args.c5_layout == "block")
     batch = pm.api.PairBatch(local_rank, args.lanes, n, n, dim)
     batch.set_option(pm.api.PM_OPT_RANSAC_PATH, args.ransac_path)
+    batch.set_desc_u8(u8)
     arr = batch.make_jobs(jobs)
-    flags = pm.api.PM_KNN_HINT_INTEGER
+    flags = pm.api.PM_KNN_HINT_U8
 
     def fence():
         if world > 1:
@@ -117,7 +138,7 @@ def bench_c5(args, world, rank, local_rank, dev, multi, saved_stdout):
         ok = True
         for j in (0, min(1, len(my_pairs) - 1)):
             w = synth.pair_workload(n, n, dim, seed=0xC5 + my_pairs[j % distinct], kind="sift")
-            knn = O.bf_knn_l2(w["q"], w["t"], 2, nthreads=8)
+            knn = O.bf_knn_l2(w["q"], w["t"], 2, nthreads=8)            # (u8 rows hold the same values)
             good = O.filter_ratio(knn, ratio)
             rc, F_o, mask_o, ninl_o, key_o = O.ransac_fundamental(w["kp1"][good["queryIdx"]], w["kp2"][good["trainIdx"]],
                                                                   H, thresh, seed, nthreads=8)
@@ -134,7 +155,7 @@ def bench_c5(args, world, rank, local_rank, dev, multi, saved_stdout):
     P = args.pairs
     ms_per_step = wall / args.steps * 1e3
     pairs_per_s = P / (ms_per_step * 1e-3)
-    h2d = (2 * n * dim * 4 + 2 * n * 8)
+    h2d = (2 * n * dim * (1 if u8 else 4) + 2 * n * 8)
     out = {
         "metric": "descriptor-pair distances/s (BF-L2 2-NN + ratio stage); RANSAC hypotheses/s in `ransac`",
         "value": pairs_per_s * n * n, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -142,15 +163,17 @@ def bench_c5(args, world, rank, local_rank, dev, multi, saved_stdout):
         "dtype": "f32",
         "dtype_note": "f32 in/out; coarse pass f16xf16->f32 MFMA (exact for u8-valued data), refinement f32",
         "data": "synthetic",
-        "config": {"workload": "C5: batch of %d image pairs x (%d x %d SIFT-128 f32 BF-L2 2-NN + ratio 0.8 + %d-hypothesis "
-                               "RANSAC-F), end to end incl. H2D/D2H from pinned host memory, %d lanes per GPU; pairs "
-                               "sharded over ranks, no collective" % (P, n, n, H, args.lanes),
-                   "descriptors": "sift", "k": 2, "distinct_pairs_per_rank": distinct},
+        "config": {"workload": "C5: batch of %d image pairs x (%d x %d SIFT-128 %s BF-L2 2-NN + ratio 0.8 + %d-hypothesis "
+                               "RANSAC-F), end to end incl. H2D/D2H from pinned host memory, %d lanes per GPU, %s; pairs "
+                               "sharded over ranks, no collective" % (P, n, n, "u8 rows" if u8 else "f32", H, args.lanes,
+                                                                      "one copy per pair" if args.c5_layout == "block" else "four copies per pair"),
+                   "descriptors": "sift", "descriptor_rows": args.c5_desc, "pair_layout": args.c5_layout, "k": 2,
+                   "distinct_pairs_per_rank": distinct},
         "image_pairs_per_s": pairs_per_s,
         "ransac": {"hyp_per_s": pairs_per_s * H, "hypotheses": H, "n_matches": int(res[0].n_good),
                    "inliers": int(res[0].n_inliers)},
         "pcie": {"h2d_bytes_per_pair": h2d, "h2d_GBps": pairs_per_s / world * h2d / 1e9,
-                 "note": "per-GPU host->device rate sustained by the pipeline; the inputs are 4.3 MB per pair"},
+                 "note": "per-GPU host->device rate sustained by the pipeline; the inputs are %.1f MB per pair" % (h2d / 1e6)},
         "parity": parity,
     }
     print(json.dumps(out))
@@ -201,6 +224,11 @@ def main():
                     help="after the K timed steps: back-to-back steps for at least this long (clock-sustained figure)")
     ap.add_argument("--pairs", type=int, default=256, help="c5: image pairs in the whole job")
     ap.add_argument("--lanes", type=int, default=3, help="c5: streams (lanes) per GPU")
+    ap.add_argument("--c5-desc", default="f32", choices=["f32", "u8"],
+                    help="c5: descriptor rows on the host: f32 (BASELINE's, the headline) or u8 (the same values as bytes: a quarter "
+                         "of the link traffic, pm_batch_set_desc_type)")
+    ap.add_argument("--c5-layout", default="block", choices=["block", "separate"],
+                    help="c5: a pair's four host arrays in one pinned block (one copy per pair) or separate (four copies)")
     ap.add_argument("--exercise-exchange", action="store_true",
                     help="debugging: run the N>1 code path (all-gather, concat, key all-reduce, model from key) "
                          "even with one rank")

@@ -148,6 +148,18 @@ int pm_bf_knn_l2_f32(pm_ctx* ctx, const float* q, int nq, const float* t, int nt
 int pm_bf_knn_l2_f32_dev(pm_ctx* ctx, const float* d_q, int nq, const float* d_t, int nt,
                          int dim, int k, int flags, pm_match* d_out);
 
+/* The same matcher on u8 DESCRIPTOR ROWS (nq x dim / nt x dim bytes, 4-byte aligned device pointers in the _dev forms):
+ * what a SIFT extractor holds before it widens to float, a quarter of the bytes on the host link (BASELINE config 5).
+ * Output = pm_bf_knn_l2_f32 on the same values converted to float, bit for bit (distances are the canonical f32 ones).
+ * dim % 4 == 0, dim <= 128, k <= 2: the u8 route (i8 matrix cores on x - 128, integer refinement); anything else is
+ * widened on the device and takes the f32 matcher.  pm_bf_knn_l2_u8_ratio_dev: + ratio test + compaction + gather, as
+ * pm_bf_knn_l2_ratio_dev (the record buffer d_knn is required). */
+int pm_bf_knn_l2_u8(pm_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int dim, int k, pm_match* out);
+int pm_bf_knn_l2_u8_dev(pm_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int dim, int k, pm_match* d_out);
+int pm_bf_knn_l2_u8_ratio_dev(pm_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int dim, float ratio,
+                              const float* d_kp1_xy, const float* d_kp2_xy, pm_match* d_knn, pm_match* d_good,
+                              float* d_xy1, float* d_xy2, int32_t* d_n_good);
+
 /* main.cpp:46 + :49-69 (ratio form) + :77-78 + :89-91 in ONE call for batches that stay in HBM: 2-NN, ratio test
  * (d1 < ratio * d2, float multiply, strict), stable compaction in query order and keypoint gather — the outputs of
  * pm_bf_knn_l2_f32_dev(k = 2) followed by pm_filter_ratio_gather_dev, bit for bit.  d_knn (nq x 2 records) may be
@@ -393,6 +405,12 @@ typedef struct pm_batch pm_batch;   /* opaque */
 int pm_batch_create(int device, int n_lanes, int max_n1, int max_n2, int dim, pm_batch** out);
 int pm_batch_destroy(pm_batch* b);
 int pm_batch_set_option(pm_batch* b, int option, int value);     /* pm_ctx_set_option on every lane's context */
+/* Descriptor rows of the jobs: 0 = float32 (default), 1 = uint8 (desc1 / desc2 then point at n x dim BYTES; matched by
+ * pm_bf_knn_l2_u8_ratio_dev: same results as the float32 rows of the same values, a quarter of the bytes on the link).
+ * One-block jobs: when a job's four arrays lie in ONE host allocation in the order desc1 | desc2 | kp1_xy | kp2_xy
+ * (desc2 16-byte, keypoints 8-byte aligned relative to desc1, at most 768 bytes of padding in all), the pair is sent
+ * in one copy instead of four — detected per job, nothing to declare. */
+int pm_batch_set_desc_type(pm_batch* b, int desc_u8);
 int pm_batch_run(pm_batch* b, const pm_pair_job* jobs, int n_jobs, float ratio, int knn_flags,
                  const pm_ransac_params* p, pm_pair_result* results, pm_match* good, uint8_t* masks);
 /* Page-lock / release a caller-owned host buffer (hipHostRegister) so the batch copies overlap. */

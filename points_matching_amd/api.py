@@ -42,7 +42,8 @@ EXPORTS = [
     "pm_mgpu_create", "pm_mgpu_destroy", "pm_mgpu_size", "pm_mgpu_ctx", "pm_mgpu_ransac_fundamental", "pm_mgpu_match_ransac",
     "pm_mgpu_lane_ctx", "pm_mgpu_set_lanes", "pm_mgpu_set_train", "pm_mgpu_set_train_dev", "pm_mgpu_submit_dev", "pm_mgpu_collect",
     "pm_mgpu_allgather_latency", "pm_mgpu_batch_run", "pm_mgpu_batch_set_option",
-    "pm_batch_create", "pm_batch_destroy", "pm_batch_run", "pm_batch_set_option", "pm_host_register", "pm_host_unregister",
+    "pm_batch_create", "pm_batch_destroy", "pm_batch_run", "pm_batch_set_option", "pm_batch_set_desc_type",
+    "pm_bf_knn_l2_u8", "pm_bf_knn_l2_u8_dev", "pm_bf_knn_l2_u8_ratio_dev", "pm_host_register", "pm_host_unregister",
     "pm_lmeds_fundamental", "pm_lmeds_fundamental_dev", "pm_lmeds_default_iters", "pm_ransac7_adaptive",
     "pm_epipolar_residuals", "pm_f_scale_f33", "pm_epilines", "pm_epiline_endpoints",
 ]
@@ -319,6 +320,25 @@ class Context:
                                                   C.c_void_p(dF_ptr), C.c_void_p(dmask_ptr),
                                                   C.c_void_p(dninl_ptr)))
 
+    def bf_knn_l2_u8(self, q, t, k):
+        """u8 descriptor rows, host arrays (pm_bf_knn_l2_u8)."""
+        q = np.ascontiguousarray(q, np.uint8)
+        t = np.ascontiguousarray(t, np.uint8)
+        nq, dim = q.shape
+        out = np.zeros((nq, k), MATCH_DTYPE)
+        _check(lib().pm_bf_knn_l2_u8(self._h, _p(q), nq, _p(t), t.shape[0], dim, k, _p(out)))
+        return out
+
+    def bf_knn_l2_u8_dev(self, dq_ptr, nq, dt_ptr, nt, dim, k, dout_ptr):
+        _check(lib().pm_bf_knn_l2_u8_dev(self._h, C.c_void_p(dq_ptr), nq, C.c_void_p(dt_ptr), nt, dim, k, C.c_void_p(dout_ptr)))
+
+    def bf_knn_l2_u8_ratio_dev(self, dq_ptr, nq, dt_ptr, nt, dim, ratio, dkp1_ptr, dkp2_ptr, dknn_ptr, dgood_ptr, dxy1_ptr,
+                               dxy2_ptr, dn_ptr):
+        _check(lib().pm_bf_knn_l2_u8_ratio_dev(self._h, C.c_void_p(dq_ptr), nq, C.c_void_p(dt_ptr), nt, dim, C.c_float(ratio),
+                                               C.c_void_p(dkp1_ptr or 0), C.c_void_p(dkp2_ptr or 0), C.c_void_p(dknn_ptr),
+                                               C.c_void_p(dgood_ptr), C.c_void_p(dxy1_ptr or 0), C.c_void_p(dxy2_ptr or 0),
+                                               C.c_void_p(dn_ptr)))
+
     # -- matcher (main.cpp:46) -------------------------------------------------------------------
     def bf_knn_l2(self, q, t, k, flags=0):
         q = np.ascontiguousarray(q, np.float32)
@@ -475,6 +495,10 @@ class PairBatch:
 
     def set_option(self, option, value):
         _check(lib().pm_batch_set_option(self._h, option, value))
+
+    def set_desc_u8(self, on=True):
+        """the jobs' desc1 / desc2 point at uint8 rows"""
+        _check(lib().pm_batch_set_desc_type(self._h, int(bool(on))))
 
     @staticmethod
     def make_jobs(jobs):

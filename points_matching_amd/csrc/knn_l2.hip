@@ -354,6 +354,65 @@ __global__ __launch_bounds__(256) void knn_l2_prep8(const float* __restrict__ Q,
     }
 }
 
+// The same for u8 INPUT rows (pm_bf_knn_l2_u8: descriptors that never were floats — BASELINE config 5 streams a quarter
+// of the bytes): centring is one XOR per dword, the norm one v_dot4_i32_i8 of the centred bytes with themselves, and there is
+// no premise to verify.  Rows of `dim` bytes, dim % 4 == 0, dim <= 128, 4-byte aligned.
+__global__ __launch_bounds__(256) void knn_l2_prep8_u8(const uint8_t* __restrict__ Q, int nq, int nq_pad,
+                                                       const uint8_t* __restrict__ T, int nt, int nt_pad, int dim,
+                                                       float* __restrict__ qnorm, float* __restrict__ tnorm,
+                                                       uint2* __restrict__ Q8, uint2* __restrict__ T8, int* __restrict__ seeds)
+{
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int qblocks = nq_pad / 64;
+    const bool is_t = static_cast<int>(blockIdx.x) >= qblocks;
+    const uint8_t* x = is_t ? T : Q;
+    const int n = is_t ? nt : nq;
+    uint2* x8 = is_t ? T8 : Q8;
+    const int row0 = (is_t ? blockIdx.x - qblocks : blockIdx.x) * 64;
+    const int c0 = 8 * sub;
+    unsigned ld[4][2];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = row0 + it * 16 + grp;
+        const uint8_t* p = x + static_cast<size_t>(row < n ? row : n - 1) * dim;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int c = c0 + 4 * e < dim ? c0 + 4 * e : dim - 4;
+            ld[it][e] = *reinterpret_cast<const unsigned*>(p + c);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = row0 + it * 16 + grp;
+        const bool live = row < n;
+        unsigned w[2];
+        int si = 0;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            w[e] = (live && c0 + 4 * e < dim) ? (ld[it][e] ^ 0x80808080u) : 0u;
+            si = __builtin_amdgcn_sdot4(static_cast<int>(w[e]), static_cast<int>(w[e]), si, false);
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) si += __shfl_xor(si, o, 16);
+        x8[static_cast<size_t>(row) * (U8_DP / 8) + sub] = uint2{w[0], w[1]};
+        if (sub == 0) {
+            if (is_t) {
+                seeds[seed_pos(row)] = live ? -(si >> 1) : U8_PAD_SEED;
+                if (live) tnorm[row] = static_cast<float>(si);
+            } else if (live) {
+                qnorm[row] = static_cast<float>(si);
+            }
+        }
+    }
+}
+
+// u8 rows -> f32 rows (shapes the u8 route does not take: the f32 matcher then runs on the widened copies, same bits)
+__global__ __launch_bounds__(256) void knn_u8_widen(const uint8_t* __restrict__ x, size_t n, float* __restrict__ y)
+{
+    for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * 256)
+        y[i] = static_cast<float>(x[i]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // f16 route for GENERAL floats (automatic mode, data that failed the integer premise — e.g. SURF's unit-norm
 // descriptors, main.cpp:37-40): the same f16 coarse kernel on f16-ROUNDED copies, 16x the f32 matrix rate, with the
@@ -1252,13 +1311,21 @@ int kf_prepare(pm_ctx* ctx, int nq, KnnFuse& fz)
 
 // the matcher; `fuse` (k == 2): ratio test + compaction + gather ride the refinement launch (MFMA routes) or follow as
 // pm_filter_ratio_gather_dev (exact kernel)
+// uq / ut != null: the rows are u8 (pm_bf_knn_l2_u8); only the u8 route takes them — the return value 2 tells the caller
+// that this shape needs the f32 path on widened copies (dq / dt are not read in that mode).
 int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt, int dim, int k, int flags, pm_match* dout,
-                   KnnFuse* fuse)
+                   KnnFuse* fuse, const uint8_t* uq = nullptr, const uint8_t* ut = nullptr)
 {
+    const bool u8in = uq != nullptr;
+    if (u8in) {
+        const bool al = ((reinterpret_cast<uintptr_t>(uq) | reinterpret_cast<uintptr_t>(ut)) & 3) == 0;
+        if (!(k <= 2 && (dim % 4) == 0 && dim <= 128 && nt >= 1 && al && fuse == nullptr)) return 2;
+        flags = PM_KNN_HINT_U8;
+    }
 
     // the MFMA routes read rows as 16-byte vectors: dim % 4 == 0 AND 16-byte aligned base pointers (anything else
     // takes the exact kernel, whose loads are scalar unless both hold)
-    const bool aligned16 = ((reinterpret_cast<uintptr_t>(dq) | reinterpret_cast<uintptr_t>(dt)) & 15) == 0;
+    const bool aligned16 = u8in || ((reinterpret_cast<uintptr_t>(dq) | reinterpret_cast<uintptr_t>(dt)) & 15) == 0;
     const bool fast = !(flags & PM_KNN_FORCE_EXACT) && k <= 2 && (dim % 4) == 0 && dim <= 128 && nt >= 1 && aligned16;
     if (!fast) {
         const int rx = run_exact(ctx, dq, nq, dt, nt, dim, k, dout);
@@ -1339,7 +1406,10 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
     // (the u8 route's integer refinement writes k-NN records: the fused filter-in-refinement form stays on the f16 pass)
     if (route == ROUTE_U8_HINT && (lid_bits16 > U8_SHIFT || (static_cast<long long>(nt_pad) + H_TT) * U8_DP >= 0x7FFFFFFFLL ||
                                    seeded_opt == 1 || fuse != nullptr))
+    {
+        if (u8in) return 2;                                     // (u8 rows: the caller widens and takes the f32 entry point)
         route = ROUTE_F16_HINT;                                 // u8-valued data satisfy the integer premise too
+    }
     // rows per candidate group of the u8 route: PM_OPT_KNN_U8_GROUP 1 / 2 / 3 = 4 / 8 / 16 (0: 8)
     const int u8_group = ctx->opts[PM_OPT_KNN_U8_GROUP] == 1 ? 4 : (ctx->opts[PM_OPT_KNN_U8_GROUP] == 3 ? 16 : 8);
     // u8 refinement: integer re-evaluation on the byte copies (default) or the canonical f32 kernel (4-row groups only)
@@ -1354,6 +1424,7 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
         g16.int_shift = U8_SHIFT;
         g16.embed_coef = 0.f;
     }
+    if (u8in && !(route == ROUTE_U8_HINT && u8_int_refine)) return 2;
     if ((want32 && lid_bits32 > 16) || (want16 && lid_bits16 > 16)) {    // > 64k rows per lane stream
         const int rx = run_exact(ctx, dq, nq, dt, nt, dim, k, dout);
         return rx == PM_OK && fuse ? 1 : rx;
@@ -1407,7 +1478,11 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
     }
     {
         pm::ScopedKernelTime t(ctx, "knn_l2_prep");
-        if (u8r)
+        if (u8in)
+            hipLaunchKernelGGL(knn_l2_prep8_u8, dim3(nq_pad / 64 + nt_pad / 64), dim3(256), 0, ctx->stream, uq, nq, nq_pad, ut, nt,
+                               nt_pad, dim, qnorm, tnorm, reinterpret_cast<uint2*>(Qh), reinterpret_cast<uint2*>(Th),
+                               static_cast<int*>(seeds));
+        else if (u8r)
             hipLaunchKernelGGL(knn_l2_prep8, dim3(nq_pad / 64 + nt_pad / 64), dim3(256), 0, ctx->stream, dq, nq, nq_pad, dt,
                                nt, nt_pad, dim, qnorm, tnorm, reinterpret_cast<uint2*>(Qh), reinterpret_cast<uint2*>(Th),
                                static_cast<int*>(seeds), stats, epoch);
@@ -1536,6 +1611,105 @@ extern "C" int pm_bf_knn_l2_ratio_dev(pm_ctx* ctx, const float* d_q, int nq, con
     rc = knn_l2_enqueue(ctx, d_q, nq, d_t, nt, dim, 2, flags, d_knn, nullptr);
     if (rc != PM_OK) return rc;
     return pm_filter_ratio_gather_dev(ctx, d_knn, nq, 2, ratio, d_kp1_xy, d_kp2_xy, d_good, d_xy1, d_xy2, d_n_good);
+}
+
+// ---- u8 descriptor rows (pm_bf_knn_l2_u8*): the u8 route with nothing to convert but one XOR; other shapes go through
+// the f32 matcher on widened copies.  Result = pm_bf_knn_l2_f32 on the same values, bit for bit.
+namespace {
+int u8_widened(pm_ctx* ctx, const uint8_t* dq, int nq, const uint8_t* dt, int nt, int dim, const float** fq, const float** ft)
+{
+    const size_t a = pm::align_up(static_cast<size_t>(nq) * dim, 64), b = static_cast<size_t>(nt) * dim;
+    if ((a + b) * sizeof(float) > ctx->widen_cap) {
+        PM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (ctx->widen) PM_HIP_CHECK(hipFree(ctx->widen));
+        ctx->widen = nullptr;
+        ctx->widen_cap = 0;
+        const size_t cap = pm::align_up((a + b) * sizeof(float) * 5 / 4, size_t(1) << 20);
+        PM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ctx->widen), cap));
+        ctx->widen_cap = cap;
+    }
+    if (static_cast<size_t>(nq) * dim)
+        hipLaunchKernelGGL(knn_u8_widen, dim3(256), dim3(256), 0, ctx->stream, dq, static_cast<size_t>(nq) * dim, ctx->widen);
+    if (b) hipLaunchKernelGGL(knn_u8_widen, dim3(256), dim3(256), 0, ctx->stream, dt, b, ctx->widen + a);
+    PM_HIP_CHECK(hipGetLastError());
+    *fq = ctx->widen;
+    *ft = ctx->widen + a;
+    return PM_OK;
+}
+}  // namespace
+
+extern "C" int pm_bf_knn_l2_u8_dev(pm_ctx* ctx, const uint8_t* dq, int nq, const uint8_t* dt, int nt, int dim, int k,
+                                   pm_match* dout)
+{
+    PM_REQUIRE(ctx != nullptr, PM_E_INVALID, "ctx is null");
+    PM_REQUIRE(nq >= 0 && nt >= 0 && dim >= 1 && k >= 1 && k <= PM_MAX_K, PM_E_INVALID,
+               "need nq,nt >= 0, dim >= 1, 1 <= k <= PM_MAX_K");
+    PM_REQUIRE(nq == 0 || (dq && dout), PM_E_INVALID, "null query/output pointer");
+    PM_REQUIRE(nt == 0 || dt, PM_E_INVALID, "null train pointer");
+    if (nq == 0) return PM_OK;
+    PM_HIP_CHECK(hipSetDevice(ctx->device));
+    int rc = nt >= 1 ? knn_l2_enqueue(ctx, nullptr, nq, nullptr, nt, dim, k, 0, dout, nullptr, dq, dt) : 2;
+    if (rc != 2) return rc;
+    const float *fq = nullptr, *ft = nullptr;
+    rc = u8_widened(ctx, dq, nq, dt, nt, dim, &fq, &ft);
+    if (rc != PM_OK) return rc;
+    return knn_l2_enqueue(ctx, fq, nq, ft, nt, dim, k, PM_KNN_HINT_INTEGER, dout, nullptr);
+}
+
+extern "C" int pm_bf_knn_l2_u8_ratio_dev(pm_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int dim, float ratio,
+                                         const float* d_kp1_xy, const float* d_kp2_xy, pm_match* d_knn, pm_match* d_good,
+                                         float* d_xy1, float* d_xy2, int32_t* d_n_good)
+{
+    PM_REQUIRE(ctx != nullptr && d_n_good != nullptr && d_knn != nullptr, PM_E_INVALID, "null argument (the u8 form needs the record buffer)");
+    PM_REQUIRE(nq >= 0 && nt >= 0 && dim >= 1, PM_E_INVALID, "need nq,nt >= 0, dim >= 1");
+    PM_REQUIRE(nq == 0 || (d_q && d_good), PM_E_INVALID, "null query/output pointer");
+    PM_REQUIRE((d_kp1_xy == nullptr) == (d_kp2_xy == nullptr), PM_E_INVALID, "give both keypoint arrays or none");
+    PM_REQUIRE(d_kp1_xy == nullptr || (d_xy1 && d_xy2), PM_E_INVALID, "null point outputs");
+    PM_HIP_CHECK(hipSetDevice(ctx->device));
+    if (nq == 0) {
+        PM_HIP_CHECK(hipMemsetAsync(d_n_good, 0, sizeof(int32_t), ctx->stream));
+        return PM_OK;
+    }
+    const int rc = pm_bf_knn_l2_u8_dev(ctx, d_q, nq, d_t, nt, dim, 2, d_knn);
+    if (rc != PM_OK) return rc;
+    return pm_filter_ratio_gather_dev(ctx, d_knn, nq, 2, ratio, d_kp1_xy, d_kp2_xy, d_good, d_xy1, d_xy2, d_n_good);
+}
+
+extern "C" int pm_bf_knn_l2_u8(pm_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int dim, int k, pm_match* out)
+{
+    PM_REQUIRE(ctx != nullptr, PM_E_INVALID, "ctx is null");
+    PM_REQUIRE(nq >= 0 && nt >= 0 && dim >= 1 && k >= 1 && k <= PM_MAX_K, PM_E_INVALID,
+               "need nq,nt >= 0, dim >= 1, 1 <= k <= PM_MAX_K");
+    PM_REQUIRE(nq == 0 || (q && out), PM_E_INVALID, "null query/output pointer");
+    PM_REQUIRE(nt == 0 || t, PM_E_INVALID, "null train pointer");
+    if (nq == 0) return PM_OK;
+    PM_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t qb = static_cast<size_t>(nq) * dim, tb = static_cast<size_t>(nt) * dim;
+    const size_t ob = sizeof(pm_match) * static_cast<size_t>(nq) * k;
+    uint8_t *dq = nullptr, *dt = nullptr;
+    pm_match* dout = nullptr;
+    int rc = PM_OK;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&dq), qb);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dt), tb ? tb : 16);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dout), ob);
+    if (e != hipSuccess) { pm::set_error("hipMalloc failed: %s", hipGetErrorString(e)); rc = PM_E_NOMEM; }
+    if (rc == PM_OK) {
+        e = hipMemcpyAsync(dq, q, qb, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess && tb) e = hipMemcpyAsync(dt, t, tb, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) { pm::set_error("H2D copy failed: %s", hipGetErrorString(e)); rc = PM_E_HIP; }
+    }
+    if (rc == PM_OK) rc = pm_bf_knn_l2_u8_dev(ctx, dq, nq, dt, nt, dim, k, dout);
+    if (rc == PM_OK) {
+        e = hipMemcpyAsync(out, dout, ob, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { pm::set_error("D2H copy failed: %s", hipGetErrorString(e)); rc = PM_E_HIP; }
+    } else {
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    (void)hipFree(dq);
+    (void)hipFree(dt);
+    (void)hipFree(dout);
+    return rc;
 }
 
 extern "C" int pm_bf_knn_l2_f32(pm_ctx* ctx, const float* q, int nq, const float* t, int nt, int dim, int k,

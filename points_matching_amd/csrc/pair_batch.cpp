@@ -22,6 +22,10 @@ struct DevResult {            // one D2H copy per pair
 
 struct Lane {
     pm_ctx* ctx = nullptr;
+    // the inputs of a pair live in ONE device block (din: descriptors 1 | descriptors 2 | keypoints 1 | keypoints 2 at their
+    // maximal sizes), so that a job whose four host arrays are one contiguous block travels in ONE copy
+    char* din = nullptr;
+    size_t din_cap = 0;
     float *dq = nullptr, *dt = nullptr, *dkp1 = nullptr, *dkp2 = nullptr, *dxy1 = nullptr, *dxy2 = nullptr;
     pm_match *dknn = nullptr, *dgood = nullptr;
     uint8_t* dmask = nullptr;
@@ -39,6 +43,7 @@ struct Lane {
 
 struct pm_batch {
     int device = 0, n_lanes = 0, max_n1 = 0, max_n2 = 0, dim = 0;
+    int desc_u8 = 0;              // pm_batch_set_desc_type: the jobs' descriptor rows are bytes
     Lane* lanes = nullptr;
 };
 
@@ -47,7 +52,7 @@ namespace {
 int lane_free(Lane& L)
 {
     if (L.ctx) (void)hipStreamSynchronize(L.ctx->stream);
-    (void)hipFree(L.dq); (void)hipFree(L.dt); (void)hipFree(L.dkp1); (void)hipFree(L.dkp2);
+    (void)hipFree(L.din);
     (void)hipFree(L.dxy1); (void)hipFree(L.dxy2); (void)hipFree(L.dknn); (void)hipFree(L.dgood);
     (void)hipFree(L.dmask); (void)hipFree(L.dres);
     if (L.hres) (void)hipHostFree(L.hres);
@@ -64,10 +69,16 @@ int lane_init(Lane& L, int device, int max_n1, int max_n2, int dim)
     int rc = pm_ctx_create(device, &L.ctx);
     if (rc != PM_OK) return rc;
     const size_t n1 = static_cast<size_t>(max_n1), n2 = static_cast<size_t>(max_n2);
-    PM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&L.dq), sizeof(float) * n1 * dim));
-    PM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&L.dt), sizeof(float) * n2 * dim));
-    PM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&L.dkp1), sizeof(float) * 2 * n1));
-    PM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&L.dkp2), sizeof(float) * 2 * n2));
+    {
+        const size_t a = pm::align_up(sizeof(float) * n1 * dim, 256), b = pm::align_up(sizeof(float) * n2 * dim, 256);
+        const size_t c = pm::align_up(sizeof(float) * 2 * n1, 256), d = pm::align_up(sizeof(float) * 2 * n2, 256);
+        L.din_cap = a + b + c + d + 1024;                     // (+ the alignment gaps a one-block job may carry)
+        PM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&L.din), L.din_cap));
+        L.dq = reinterpret_cast<float*>(L.din);
+        L.dt = reinterpret_cast<float*>(L.din + a);
+        L.dkp1 = reinterpret_cast<float*>(L.din + a + b);
+        L.dkp2 = reinterpret_cast<float*>(L.din + a + b + c);
+    }
     PM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&L.dxy1), sizeof(float) * 2 * n1));
     PM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&L.dxy2), sizeof(float) * 2 * n1));
     PM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&L.dknn), sizeof(pm_match) * 2 * n1));
@@ -130,6 +141,13 @@ extern "C" int pm_batch_set_option(pm_batch* b, int option, int value)
     return PM_OK;
 }
 
+extern "C" int pm_batch_set_desc_type(pm_batch* b, int desc_u8)
+{
+    PM_REQUIRE(b != nullptr && (desc_u8 == 0 || desc_u8 == 1), PM_E_INVALID, "descriptor type: 0 = float32 rows, 1 = uint8 rows");
+    b->desc_u8 = desc_u8;
+    return PM_OK;
+}
+
 extern "C" int pm_batch_destroy(pm_batch* b)
 {
     if (!b) return PM_OK;
@@ -170,13 +188,38 @@ extern "C" int pm_batch_run(pm_batch* b, const pm_pair_job* jobs, int n_jobs, fl
         const pm_pair_job& jb = jobs[j];
         hipStream_t s = L.ctx->stream;
         const size_t n1 = static_cast<size_t>(jb.n1), n2 = static_cast<size_t>(jb.n2);
-        PM_BATCH_HIP(hipMemcpyAsync(L.dq, jb.desc1, sizeof(float) * n1 * b->dim, hipMemcpyHostToDevice, s));
-        PM_BATCH_HIP(hipMemcpyAsync(L.dt, jb.desc2, sizeof(float) * n2 * b->dim, hipMemcpyHostToDevice, s));
-        PM_BATCH_HIP(hipMemcpyAsync(L.dkp1, jb.kp1_xy, sizeof(float) * 2 * n1, hipMemcpyHostToDevice, s));
-        PM_BATCH_HIP(hipMemcpyAsync(L.dkp2, jb.kp2_xy, sizeof(float) * 2 * n2, hipMemcpyHostToDevice, s));
-        if (rc == PM_OK)
-            rc = pm_bf_knn_l2_ratio_dev(L.ctx, L.dq, jb.n1, L.dt, jb.n2, b->dim, knn_flags, ratio, L.dkp1, L.dkp2, L.dknn, L.dgood,
-                                        L.dxy1, L.dxy2, &L.dres->n_good);
+        const size_t esz = b->desc_u8 ? 1 : sizeof(float);
+        const size_t qb = esz * n1 * b->dim, tb = esz * n2 * b->dim, k1b = sizeof(float) * 2 * n1, k2b = sizeof(float) * 2 * n2;
+        // One block?  desc1 | desc2 | kp1 | kp2 in this order inside one host allocation, sections aligned for the kernels'
+        // vector loads and (nearly) gap-free: the pair then travels in ONE copy (a 4k x 4k f32 pair: 4.3 MB instead of
+        // 2 + 2 + 0.03 + 0.03 MB — the link's rate grows with the copy size), at the host's own offsets.
+        const char* h0 = reinterpret_cast<const char*>(jb.desc1);
+        const ptrdiff_t ot = reinterpret_cast<const char*>(jb.desc2) - h0, o1 = reinterpret_cast<const char*>(jb.kp1_xy) - h0,
+                        o2 = reinterpret_cast<const char*>(jb.kp2_xy) - h0;
+        const bool one_block = ot >= static_cast<ptrdiff_t>(qb) && o1 >= ot + static_cast<ptrdiff_t>(tb) &&
+                               o2 >= o1 + static_cast<ptrdiff_t>(k1b) && (ot & 15) == 0 && (o1 & 7) == 0 && (o2 & 7) == 0 &&
+                               static_cast<size_t>(o2) + k2b <= qb + tb + k1b + k2b + 768 && static_cast<size_t>(o2) + k2b <= L.din_cap;
+        const void *dq = L.dq, *dt = L.dt;
+        const float *dkp1 = L.dkp1, *dkp2 = L.dkp2;
+        if (one_block) {
+            PM_BATCH_HIP(hipMemcpyAsync(L.din, h0, static_cast<size_t>(o2) + k2b, hipMemcpyHostToDevice, s));
+            dq = L.din; dt = L.din + ot;
+            dkp1 = reinterpret_cast<const float*>(L.din + o1);
+            dkp2 = reinterpret_cast<const float*>(L.din + o2);
+        } else {
+            PM_BATCH_HIP(hipMemcpyAsync(L.dq, jb.desc1, qb, hipMemcpyHostToDevice, s));
+            PM_BATCH_HIP(hipMemcpyAsync(L.dt, jb.desc2, tb, hipMemcpyHostToDevice, s));
+            PM_BATCH_HIP(hipMemcpyAsync(L.dkp1, jb.kp1_xy, k1b, hipMemcpyHostToDevice, s));
+            PM_BATCH_HIP(hipMemcpyAsync(L.dkp2, jb.kp2_xy, k2b, hipMemcpyHostToDevice, s));
+        }
+        if (rc == PM_OK) {
+            if (b->desc_u8)
+                rc = pm_bf_knn_l2_u8_ratio_dev(L.ctx, static_cast<const uint8_t*>(dq), jb.n1, static_cast<const uint8_t*>(dt), jb.n2,
+                                               b->dim, ratio, dkp1, dkp2, L.dknn, L.dgood, L.dxy1, L.dxy2, &L.dres->n_good);
+            else
+                rc = pm_bf_knn_l2_ratio_dev(L.ctx, static_cast<const float*>(dq), jb.n1, static_cast<const float*>(dt), jb.n2, b->dim,
+                                            knn_flags, ratio, dkp1, dkp2, L.dknn, L.dgood, L.dxy1, L.dxy2, &L.dres->n_good);
+        }
         if (rc == PM_OK)
             rc = pm_ransac_run_dev(L.ctx, L.dxy1, L.dxy2, jb.n1, &L.dres->n_good, p, &L.dres->key, L.dres->F, L.dmask,
                                    &L.dres->n_inliers);

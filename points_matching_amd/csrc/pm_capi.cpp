@@ -169,6 +169,7 @@ int pm_ctx_destroy(pm_ctx* ctx)
     if (ctx->fg_counts) (void)hipFree(ctx->fg_counts);
     if (ctx->sync_words) (void)hipFree(ctx->sync_words);
     if (ctx->kf_tile) (void)hipFree(ctx->kf_tile);
+    if (ctx->widen) (void)hipFree(ctx->widen);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;

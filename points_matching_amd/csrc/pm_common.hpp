@@ -77,6 +77,9 @@ struct pm_ctx {
     // arrival tickets / counters of the one-launch RANSAC kernels; every launch returns them to zero
     int* sync_words = nullptr;
     int opts[PM_OPT_COUNT_] = {};          // pm_ctx_set_option
+    // f32 copies of u8 descriptor rows for the shapes pm_bf_knn_l2_u8 hands to the f32 matcher (grow-only)
+    float* widen = nullptr;
+    size_t widen_cap = 0;
 };
 
 namespace pm {

@@ -170,3 +170,47 @@ def test_cli_image_pair_in(tmp_path):
     assert out2.returncode == 0, out2.stderr
     js2 = json.loads(out2.stdout.splitlines()[-1])
     assert js2["matches"] >= 8
+
+
+def test_cli_image_pair_pinned_to_its_fixture(tmp_path):
+    """tests/golden/img_half_cli.npz (made by tests/golden/make_img_cli_fixture.py): the keypoints / u8 descriptors the C++
+    front end finds in the two half-resolution photographs and the ORACLE's match list, inlier mask, winning hypothesis
+    and F for them.  (1) pm_cli on the fixture's descriptors must reproduce every one of those bits through the HIP path;
+    (2) pm_cli --img1/--img2 must find the same features again on this machine (another CPU's libm may move a descriptor
+    level: the comparison of (2) allows that, (1) allows nothing)."""
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(gold, "img_half_cli.npz"), allow_pickle=False)
+    iters, seed = int(g["params"][0]), int(g["params"][1])
+    p = {}
+    for name, arr in (("d1", g["desc1"].astype(np.float32)), ("d2", g["desc2"].astype(np.float32)), ("k1", g["kp1"]), ("k2", g["kp2"])):
+        p[name] = str(tmp_path / (name + ".pmm"))
+        io.save_pmm(p[name], arr)
+    base = ["--filter", "ratio", "--ratio", "0.8", "--method", "ransac8", "--iters", str(iters), "--seed", str(seed), "--thresh", "1.0",
+            "--f-scale", "unit", "--json"]
+    out = subprocess.run([build.HOST_BIN, "--desc1", p["d1"], "--desc2", p["d2"], "--kp1", p["k1"], "--kp2", p["k2"]] + base,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.splitlines()
+    n = g["ratio_query"].size
+    want = ["Good Matches are:"] + ["-- Good Match [%d] Keypoint 1: %d  -- Keypoint 2: %d  " % (i, g["ratio_query"][i], g["ratio_train"][i])
+                                    for i in range(n)]
+    assert lines[:n + 1] == want
+    js = json.loads(lines[-1])
+    key = int(g["key"][0])
+    assert js["matches"] == n and js["inliers"] == int(g["mask"].sum()) == key >> 32
+    assert js["best_hyp"] == 0xFFFFFFFF - (key & 0xFFFFFFFF) and js["ransac_status"] == 0
+    assert (np.array(js["F"], np.float64).view(np.uint64) == g["F_bits"]).all()
+    # (2) image pair in
+    pre = str(tmp_path / "f")
+    out2 = subprocess.run([build.HOST_BIN, "--img1", os.path.join(gold, "img01_half.pgm"), "--img2", os.path.join(gold, "img02_half.pgm"),
+                           "--save-features", pre] + base, capture_output=True, text=True, timeout=300)
+    assert out2.returncode == 0, out2.stderr
+    d1, d2 = io.load_pmm(pre + "_desc1.pmm"), io.load_pmm(pre + "_desc2.pmm")
+    k1 = io.load_pmm(pre + "_kp1.pmm")
+    assert d1.shape == g["desc1"].shape and d2.shape == g["desc2"].shape and np.abs(k1 - g["kp1"]).max() < 1e-3
+    assert (np.abs(d1.astype(np.int32) - g["desc1"].astype(np.int32)) <= 1).all() and (d1 == g["desc1"]).mean() > 0.999
+    js2 = json.loads(out2.stdout.splitlines()[-1])
+    if (d1 == g["desc1"]).all() and (d2 == g["desc2"]).all():
+        assert out2.stdout.splitlines()[:n + 1] == want and js2["inliers"] == js["inliers"] and js2["F"] == js["F"]
+    else:
+        assert abs(js2["matches"] - n) <= 3 and js2["inliers"] >= 0.9 * js["inliers"]

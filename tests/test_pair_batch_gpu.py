@@ -100,3 +100,57 @@ def test_batch_at_config_c5_size(oracle):
         assert (good[j, :r.n_good]["trainIdx"] == g_o["trainIdx"]).all() and (good[j, :r.n_good]["queryIdx"] == g_o["queryIdx"]).all()
         assert (np.array(r.F[:]).view(np.uint64) == F_o.reshape(9).view(np.uint64)).all(), j
         assert (masks[j, :r.n_good] == mask_o).all(), j
+
+
+def _block_of(w, desc_dtype):
+    """One host allocation desc1 | desc2 | kp1 | kp2 (256-byte aligned sections) and the job tuple pointing into it."""
+    parts = [np.ascontiguousarray(w["q"].astype(desc_dtype)), np.ascontiguousarray(w["t"].astype(desc_dtype)),
+             np.ascontiguousarray(w["kp1"], np.float32), np.ascontiguousarray(w["kp2"], np.float32)]
+    offs, total = [], 0
+    for p in parts:
+        total = (total + 255) // 256 * 256
+        offs.append(total)
+        total += p.nbytes
+    blk = np.zeros(total + 512, np.uint8)
+    base = (-blk.ctypes.data) % 256                       # 256-byte aligned start inside the allocation
+    for p, o in zip(parts, offs):
+        blk[base + o:base + o + p.nbytes] = p.view(np.uint8).reshape(-1)
+    addr = blk.ctypes.data + base
+    return blk, (addr + offs[0], w["q"].shape[0], addr + offs[1], w["t"].shape[0], addr + offs[2], addr + offs[3])
+
+
+@pytest.mark.parametrize("desc", ["f32", "u8"])
+def test_batch_one_block_jobs_and_u8_rows_equal_the_f32_batch(oracle, desc):
+    """pm_batch_set_desc_type(1): uint8 descriptor rows; one-block jobs: the four arrays of a pair in one allocation travel in
+    one copy.  Same results as the float32 four-copy batch, pair for pair and bit for bit."""
+    ws = _pairs()
+    max1, max2 = max(s[0] for s in SIZES), max(s[1] for s in SIZES)
+    b = pm.api.PairBatch(0, 2, max1, max2, 128)
+    jobs = [(w["q"].ctypes.data, w["q"].shape[0], w["t"].ctypes.data, w["t"].shape[0], w["kp1"].ctypes.data, w["kp2"].ctypes.data) for w in ws]
+    want, g_w, m_w = b.run(jobs, RATIO, H, TAU, SEED, knn_flags=pm.api.PM_KNN_HINT_U8, want_good=True, want_masks=True)
+    held = [_block_of(w, np.float32 if desc == "f32" else np.uint8) for w in ws]
+    b.set_desc_u8(desc == "u8")
+    got, g_g, m_g = b.run([h[1] for h in held], RATIO, H, TAU, SEED, knn_flags=pm.api.PM_KNN_HINT_U8, want_good=True, want_masks=True)
+    b.close()
+    for j in range(len(ws)):
+        assert (got[j].status, got[j].best_key, got[j].n_good, got[j].n_inliers, bytes(got[j].F)) == \
+               (want[j].status, want[j].best_key, want[j].n_good, want[j].n_inliers, bytes(want[j].F)), (desc, j)
+        ng = want[j].n_good
+        assert (g_g[j, :ng] == g_w[j, :ng]).all() and (m_g[j] == m_w[j]).all()
+
+
+@pytest.mark.parametrize("nq,nt,dim,k", [(700, 900, 128, 2), (1, 300, 128, 1), (300, 1, 128, 2), (129, 130, 32, 2), (50, 70, 12, 2),
+                                         (2048, 2048, 128, 2), (40, 90, 7, 2), (64, 100, 128, 5), (20, 200, 200, 3), (513, 2049, 64, 1)])
+def test_knn_l2_u8_rows_equal_the_f32_matcher(ctx, oracle, nq, nt, dim, k):
+    """pm_bf_knn_l2_u8: uint8 rows in, the records of pm_bf_knn_l2_f32 on the same values out — the u8 route where it applies
+    (dim % 4 == 0, dim <= 128, k <= 2), widened copies through the f32 matcher elsewhere."""
+    rng = np.random.default_rng(nq * 31 + nt)
+    if dim == 128:
+        qf, tf, _ = synth.sift_like(nq, nt, dim, seed=nq + nt)
+        q, t = qf.astype(np.uint8), tf.astype(np.uint8)
+    else:
+        q = rng.integers(0, 256, (nq, dim), dtype=np.uint8)
+        t = rng.integers(0, 256, (nt, dim), dtype=np.uint8)
+    want = oracle.bf_knn_l2(q.astype(np.float32), t.astype(np.float32), k, nthreads=8)
+    from util import assert_matches_equal
+    assert_matches_equal(ctx.bf_knn_l2_u8(q, t, k), want, "u8 rows %s" % ((nq, nt, dim, k),))
