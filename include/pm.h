@@ -110,7 +110,9 @@ enum {
     PM_OPT_KNN_U8_REFINE  = 13, /* u8 route refinement: 1 = canonical f32 kernel (4-row groups only), 2 = integer
                                    re-evaluation on the byte copies, one lane per row (default)                     */
     PM_OPT_KNN_RING_PROLOGUE = 14, /* u8 ring kernel: train tiles requested before the sweep starts, 2 .. 8 (default 2)    */
-    PM_OPT_COUNT_         = 15
+    PM_OPT_KNN_WIDE       = 15, /* L2 matcher beyond dim % 4 == 0 && dim <= 128 && 16-byte aligned rows: 1 = exact VALU kernel (round 2),
+                                   2 = f16 matrix passes on padded copies, up to 256 dimensions (default)             */
+    PM_OPT_COUNT_         = 16
 };
 int  pm_ctx_set_option(pm_ctx* ctx, int option, int value);
 int  pm_ctx_get_option(pm_ctx* ctx, int option, int* value);

@@ -14,10 +14,13 @@ int launch_coarse_f32(pm_ctx* ctx, const float* dq, int nq, const float* dt, int
 
 int launch_coarse_f16(pm_ctx* ctx, const _Float16* Qh, const _Float16* Th, int nq, int nq_pad, int nt, int splits,
                       int tiles_per_split, unsigned keep_mask, float* cval, int slots,
-                      const unsigned long long* stats, unsigned epoch, int mode)
+                      const unsigned long long* stats, unsigned epoch, int mode, int dp)
 {
+    if (dp == 256)
+        return launch_rows288<RouteF16T<256>, AblNone>(ctx, "knn_l2_mfma_f16", Qh, Th, nullptr, nq, nq_pad, nt, splits, tiles_per_split,
+                                                  keep_mask, cval, slots, stats, epoch, mode);
     return launch_rows288<RouteF16, AblNone>(ctx, "knn_l2_mfma_f16", Qh, Th, nullptr, nq, nq_pad, nt, splits, tiles_per_split, keep_mask,
-                                    cval, slots, stats, epoch, mode);
+                                        cval, slots, stats, epoch, mode);
 }
 
 int launch_coarse_i8(pm_ctx* ctx, const void* Qe, const void* Te, int nq, int nq_pad, int nt, int splits,

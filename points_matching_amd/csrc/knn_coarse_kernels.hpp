@@ -340,10 +340,15 @@ __global__ __launch_bounds__(256, (TT == 64 ? 2 : 1)) void knn_l2_mfma(
 //   RouteI8   v_mfma_i32_32x32x32_i8 on +-1 bytes (binary descriptors: dot = bits - 2*hamming),
 //             values int, candidate = (dot << I8_SHIFT) | group id.
 // `par` is the f16 route's keep mask (unused by the i8 route: its shift is a constant).
-struct RouteF16 {
-    static constexpr int NCH = H_NCH;                 // 8 data chunks + the seed chunk
-    static constexpr int ROW16 = H_ROW16;             // 16-byte units per global row
-    static constexpr int LDS_ROW16 = H_LDS_ROW16;     // ... per LDS row (one pad slot)
+// DP: padded data columns, 128 (9 k-chunks, 288-byte rows) or 256 (17 k-chunks, 544-byte rows: descriptors of up to 256
+// dimensions, round 3).  The LDS row is one 16-byte slot longer: an ODD number of slots, so the 16 rows of a
+// ds_read_b128 lane group hit 16 different slots.
+template <int DP>
+struct RouteF16T {
+    static constexpr int NCH = DP / 16 + 1;           // data chunks + the seed chunk
+    static constexpr int ROW16 = (DP + 16) / 8;       // 16-byte units per global row
+    static constexpr int LDS_ROW16 = ROW16 + 1;       // ... per LDS row (one pad slot)
+    static_assert(LDS_ROW16 % 2 == 1 && (H_TT * LDS_ROW16) % 64 == 0, "conflict-free rows, whole DMA pieces");
     static constexpr int GPB = 4;                     // row groups per 32-row block and lane: groups of 4 rows
     static constexpr bool MERGE = true;               // one list per (query, split): float ties are rare
     static constexpr bool SEEDED = false;             // the seed rides its own k-chunk
@@ -366,6 +371,8 @@ struct RouteF16 {
     static __device__ __forceinline__ void merge(list& cl, int h) { merge_halves(cl, h); }
     static __device__ __forceinline__ void put(list& cl, float x) { top4_insert(cl, x); }
 };
+typedef RouteF16T<128> RouteF16;
+static_assert(RouteF16::NCH == H_NCH && RouteF16::ROW16 == H_ROW16 && RouteF16::LDS_ROW16 == H_LDS_ROW16, "knn_shared.hpp constants");
 
 struct RouteI8 {
     static constexpr int NCH = I8_NCH;                // 8 data chunks, no seed: pad rows are all-zero (dot = 0)
@@ -674,7 +681,7 @@ __device__ __forceinline__ void h_tile(const uint4* __restrict__ tb, const uint4
 // count (and with it the refinement's input) stays that of one workgroup per CU.
 // mode bit 0: 0 = run always (hint / i8), 1 = run only if prep16 found the data eligible (auto); bit 1: XCD-tiled grid
 template <typename R, int NQB, bool DMA, int GR, typename ABL>
-__global__ __launch_bounds__(H_QB / (32 * NQB) * 64 * GR, (NQB == 2 ? 2 : 4)) void knn_mfma_rows288(
+__global__ __launch_bounds__(H_QB / (32 * NQB) * 64 * GR, (R::NCH > 9 ? (NQB == 2 ? 1 : 2) : (NQB == 2 ? 2 : 4))) void knn_mfma_rows288(
     const uint4* __restrict__ Qh, const uint4* __restrict__ Th, const uint4* __restrict__ seeds_g, int nq, int nt,
     int tiles_per_split, unsigned par, typename R::list* __restrict__ cand_val, int slots,
     const unsigned long long* __restrict__ stats, unsigned epoch, int mode)

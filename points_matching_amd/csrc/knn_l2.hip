@@ -167,7 +167,45 @@ __global__ __launch_bounds__(256) void knn_l2_prep(const float* __restrict__ Q, 
 // ---------------------------------------------------------------------------------------------
 // SEEDED (round 3, hint route): rows of 128 halfs with no seed chunk; -||t||^2/2 goes to `seeds` (seed order,
 // knn_shared.hpp) and starts the accumulators of the coarse kernel instead (RouteF16S).
-template <bool SEEDED>
+// DP (round 3): padded data columns per row, 128 or 256 — descriptors of up to 256 dimensions (and any dim: the copies
+// are zero padded, so dim % 4 != 0 only changes how the f32 rows are READ).  ALIGNED: rows read as 16-byte vectors
+// (dim % 4 == 0 and 16-byte aligned base pointers), else element by element.
+// Integer premise for DP columns: |x| <= floor(sqrt(2^24 / DP)) keeps every partial sum below 2^24 (361 / 255).
+template <int DP>
+struct F16Rows {
+    static constexpr int ROWH = DP + 16;                     // halfs per row: data + the seed chunk
+    static constexpr int NCB = DP / 128;                     // column blocks of 128 a lane group walks
+    static constexpr float MAXABS = DP == 128 ? 361.f : 255.f;
+};
+
+// the 8 columns cb + 8*sub .. +7 of one row as floats, zero beyond dim; unconditional (clamped) loads
+template <bool ALIGNED>
+struct Row8 {
+    f32x4 a, b;
+    float e[8];
+    __device__ __forceinline__ void load(const float* __restrict__ p, int c, int dim)
+    {
+        if constexpr (ALIGNED) {
+            const int c1 = c < dim ? c : dim - 4, c2 = c + 4 < dim ? c + 4 : dim - 4;      // dim % 4 == 0, dim >= 4
+            a = *reinterpret_cast<const f32x4*>(p + c1);
+            b = *reinterpret_cast<const f32x4*>(p + c2);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) e[k] = p[c + k < dim ? c + k : dim - 1];
+        }
+    }
+    __device__ __forceinline__ void get(int c, int dim, bool live, float (&v)[8]) const
+    {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float x = ALIGNED ? (k < 4 ? a[k & 3] : b[k & 3]) : e[k];
+            const bool in = ALIGNED ? (c + (k & ~3) < dim) : (c + k < dim);
+            v[k] = (live && in) ? x : 0.f;
+        }
+    }
+};
+
+template <bool SEEDED, int DP, bool ALIGNED>
 __global__ __launch_bounds__(256) void knn_l2_prep16(const float* __restrict__ Q, int nq, int nq_pad,
                                                      const float* __restrict__ T, int nt, int nt_pad, int dim,
                                                      float* __restrict__ qnorm, float* __restrict__ tnorm,
@@ -175,7 +213,9 @@ __global__ __launch_bounds__(256) void knn_l2_prep16(const float* __restrict__ Q
                                                      float* __restrict__ seeds,
                                                      unsigned long long* __restrict__ stats, unsigned epoch)
 {
-    constexpr int ROWH = SEEDED ? H_DP : H_ROW;
+    typedef F16Rows<DP> G;
+    constexpr int ROWH = SEEDED ? DP : G::ROWH;
+    constexpr int NCB = G::NCB;
     __shared__ unsigned wmax[4];
     __shared__ unsigned wbad[4];
     const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
@@ -187,44 +227,39 @@ __global__ __launch_bounds__(256) void knn_l2_prep16(const float* __restrict__ Q
     _Float16* xh = is_t ? Th : Qh;
     const int row0 = (is_t ? blockIdx.x - qblocks : blockIdx.x) * 64;
     unsigned mx = 0u, bad = 0u;
-    // all eight 16-byte loads of a thread's four rows are requested before anything is computed (unconditional, clamped
+    // all the loads of a thread's four rows are requested before anything is computed (unconditional, clamped
     // addresses: a guarded load makes hipcc wait for each in turn — four dependent memory round trips instead of one)
     const int c0 = 8 * sub;
-    f32x4 ld[4][2];
+    Row8<ALIGNED> ld[4][NCB];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int row = row0 + it * 16 + grp;
         const float* p = x + static_cast<size_t>(row < n ? row : n - 1) * dim;       // n >= 1 on this route
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int c = c0 + 4 * e < dim ? c0 + 4 * e : dim - 4;                      // dim % 4 == 0, dim >= 4
-            ld[it][e] = *reinterpret_cast<const f32x4*>(p + c);
-        }
+        for (int cb = 0; cb < NCB; ++cb) ld[it][cb].load(p, 128 * cb + c0, dim);
     }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int row = row0 + it * 16 + grp;                 // < n_pad by construction
         const bool live = row < n;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; e += 4) {
-            f32x4 u = ld[it][e >> 2];
-            if (!(live && c0 + e < dim)) u = f32x4{0.f, 0.f, 0.f, 0.f};
-            v[e] = u[0]; v[e + 1] = u[1]; v[e + 2] = u[2]; v[e + 3] = u[3];
-        }
         float s = 0.f;
         bool okrow = true;
-        f16x8 hv;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            s = fmaf(v[e], v[e], s);
-            okrow &= (v[e] == __builtin_rintf(v[e])) && (__builtin_fabsf(v[e]) <= H_MAXABS);
-            hv[e] = static_cast<_Float16>(v[e]);
+        for (int cb = 0; cb < NCB; ++cb) {
+            float v[8];
+            ld[it][cb].get(128 * cb + c0, dim, live, v);
+            f16x8 hv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s = fmaf(v[e], v[e], s);
+                okrow &= (v[e] == __builtin_rintf(v[e])) && (__builtin_fabsf(v[e]) <= G::MAXABS);
+                hv[e] = static_cast<_Float16>(v[e]);
+            }
+            *reinterpret_cast<f16x8*>(xh + static_cast<size_t>(row) * ROWH + 128 * cb + c0) = hv;
         }
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
         if (!okrow) bad |= 2u;
-        *reinterpret_cast<f16x8*>(xh + static_cast<size_t>(row) * ROWH + c0) = hv;
         if (sub == 0) {
             if (live) {
                 norm[row] = s;
@@ -252,8 +287,8 @@ __global__ __launch_bounds__(256) void knn_l2_prep16(const float* __restrict__ Q
                 e0[1] = static_cast<_Float16>(-32.f);
                 e0[2] = static_cast<_Float16>(-0.5f);
             }
-            *reinterpret_cast<f16x8*>(xh + static_cast<size_t>(row) * H_ROW + H_DP) = e0;
-            *reinterpret_cast<f16x8*>(xh + static_cast<size_t>(row) * H_ROW + H_DP + 8) = e1;
+            *reinterpret_cast<f16x8*>(xh + static_cast<size_t>(row) * G::ROWH + DP) = e0;
+            *reinterpret_cast<f16x8*>(xh + static_cast<size_t>(row) * G::ROWH + DP + 8) = e1;
         }
     }
 #pragma unroll
@@ -470,12 +505,15 @@ __global__ void knn_gen_off(unsigned long long* __restrict__ stats, unsigned epo
     if (threadIdx.x == 0) atomicMax(&stats[3], (static_cast<unsigned long long>(epoch) << 32) | 1ull);
 }
 
+template <int DP, bool ALIGNED>
 __global__ __launch_bounds__(256) void knn_l2_prep16g(const float* __restrict__ Q, int nq, int nq_pad,
                                                       const float* __restrict__ T, int nt, int nt_pad, int dim,
                                                       const float* __restrict__ qnorm, const float* __restrict__ tnorm,
                                                       _Float16* __restrict__ Qh, _Float16* __restrict__ Th,
                                                       const unsigned long long* __restrict__ stats, unsigned epoch)
 {
+    typedef F16Rows<DP> G;
+    constexpr int NCB = G::NCB;
     const unsigned long long s1 = stats[1];
     const bool flagged = static_cast<unsigned>(s1 >> 32) == epoch;
     if (!(flagged && (s1 & 2ull))) return;                  // integer-valued data: prep16's copies stand
@@ -490,7 +528,7 @@ __global__ __launch_bounds__(256) void knn_l2_prep16g(const float* __restrict__ 
     _Float16* xh = is_t ? Th : Qh;
     const int row0 = (is_t ? blockIdx.x - qblocks : blockIdx.x) * 64;
     const int c0 = 8 * sub;
-    f32x4 ld[4][2];
+    Row8<ALIGNED> ld[4][NCB];
     float nrm[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -498,10 +536,7 @@ __global__ __launch_bounds__(256) void knn_l2_prep16g(const float* __restrict__ 
         const int rr = row < n ? row : n - 1;
         const float* p = x + static_cast<size_t>(rr) * dim;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int c = c0 + 4 * e < dim ? c0 + 4 * e : dim - 4;
-            ld[it][e] = *reinterpret_cast<const f32x4*>(p + c);
-        }
+        for (int cb = 0; cb < NCB; ++cb) ld[it][cb].load(p, 128 * cb + c0, dim);
         nrm[it] = (is_t ? tnorm : qnorm)[rr];
     }
 #pragma unroll
@@ -511,14 +546,15 @@ __global__ __launch_bounds__(256) void knn_l2_prep16g(const float* __restrict__ 
         QueryScale qs = query_scale(ht, nrm[it]);
         const float sc = is_t ? st : qs.sq;
         const bool zero = !live || (!is_t && qs.unranked);
-        f16x8 hv;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float v = ld[it][e >> 2][e & 3];
-            if (zero || !(c0 + (e & ~3) < dim)) v = 0.f;
-            hv[e] = static_cast<_Float16>(v * sc);          // |v * sc| < 2^10: in range; round to nearest even
+        for (int cb = 0; cb < NCB; ++cb) {
+            float v[8];
+            ld[it][cb].get(128 * cb + c0, dim, !zero, v);
+            f16x8 hv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hv[e] = static_cast<_Float16>(v[e] * sc);     // |v * sc| < 2^10: in range; round to nearest even
+            *reinterpret_cast<f16x8*>(xh + static_cast<size_t>(row) * G::ROWH + 128 * cb + c0) = hv;
         }
-        *reinterpret_cast<f16x8*>(xh + static_cast<size_t>(row) * H_ROW + c0) = hv;
         if (sub == 0) {
             f16x8 e0 = {0, 0, 0, 0, 0, 0, 0, 0};
             const f16x8 e1 = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -541,8 +577,8 @@ __global__ __launch_bounds__(256) void knn_l2_prep16g(const float* __restrict__ 
                 e0[1] = static_cast<_Float16>(qs.qc[1]);
                 e0[2] = static_cast<_Float16>(qs.qc[2]);
             }
-            *reinterpret_cast<f16x8*>(xh + static_cast<size_t>(row) * H_ROW + H_DP) = e0;
-            *reinterpret_cast<f16x8*>(xh + static_cast<size_t>(row) * H_ROW + H_DP + 8) = e1;
+            *reinterpret_cast<f16x8*>(xh + static_cast<size_t>(row) * G::ROWH + DP) = e0;
+            *reinterpret_cast<f16x8*>(xh + static_cast<size_t>(row) * G::ROWH + DP + 8) = e1;
         }
     }
 }
@@ -550,18 +586,60 @@ __global__ __launch_bounds__(256) void knn_l2_prep16g(const float* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 // refinement: one wave per query
 // ---------------------------------------------------------------------------------------------
-struct Best2 {
-    uint64_t k0, k1;
-    float d0, d1;
-};
-
-__device__ __forceinline__ void best2_insert(Best2& b, uint64_t key, float d)
-{
-    if (key < b.k1) {
-        if (key < b.k0) { b.k1 = b.k0; b.d1 = b.d0; b.k0 = key; b.d0 = d; }
-        else { b.k1 = key; b.d1 = d; }
+// the KM smallest (key, distance) pairs a lane has seen, ascending (KM = 2 for k <= 2, 4 for k <= 4)
+template <int KM>
+struct BestN {
+    uint64_t k[KM];
+    float d[KM];
+    __device__ __forceinline__ void init()
+    {
+#pragma unroll
+        for (int i = 0; i < KM; ++i) { k[i] = ~0ull; d[i] = KNN_INF; }
     }
-}
+    __device__ __forceinline__ void insert(uint64_t key, float dist)
+    {
+        if (key < k[KM - 1]) {
+            k[KM - 1] = key; d[KM - 1] = dist;
+#pragma unroll
+            for (int i = KM - 1; i > 0; --i)
+                if (k[i] < k[i - 1]) {
+                    const uint64_t t = k[i]; k[i] = k[i - 1]; k[i - 1] = t;
+                    const float u = d[i]; d[i] = d[i - 1]; d[i - 1] = u;
+                }
+        }
+    }
+    __device__ __forceinline__ void pop()
+    {
+#pragma unroll
+        for (int i = 0; i + 1 < KM; ++i) { k[i] = k[i + 1]; d[i] = d[i + 1]; }
+        k[KM - 1] = ~0ull; d[KM - 1] = KNN_INF;
+    }
+};
+// ... and the KM smallest coarse values of a lane's slots (for the k-th smallest over the wave / row)
+template <typename V, int KM>
+struct MinN {
+    V m[KM];
+    __device__ __forceinline__ void init(V big)
+    {
+#pragma unroll
+        for (int i = 0; i < KM; ++i) m[i] = big;
+    }
+    __device__ __forceinline__ void insert(V v)
+    {
+        if (v < m[KM - 1]) {
+            m[KM - 1] = v;
+#pragma unroll
+            for (int i = KM - 1; i > 0; --i)
+                if (m[i] < m[i - 1]) { const V t = m[i]; m[i] = m[i - 1]; m[i - 1] = t; }
+        }
+    }
+    __device__ __forceinline__ void pop(V big)
+    {
+#pragma unroll
+        for (int i = 0; i + 1 < KM; ++i) m[i] = m[i + 1];
+        m[KM - 1] = big;
+    }
+};
 
 // Candidate-list geometry of one coarse route (how a slot index and the embedded row id map back
 // to a train row, and how wide the refinement window must be).
@@ -667,7 +745,9 @@ constexpr unsigned KF_SPIN_LIMIT = 1u << 22;
 // of these workgroups — 1792 of the 2048 at C3, i.e. a second round: 10 -> 20 us.  Capped, the kernel stays at 8.)
 // GEN: the automatic route may have ranked general floats on rounded copies (SPEC S1c); the other routes are
 // instantiated without that code (its scalar loads and the rescale cost the headline path 0.6 us at C3).
-template <bool VEC4, int NS, bool FUSE, bool GEN>
+// KM: neighbours a lane keeps (2: k <= 2; 4: k <= 4 — the coarse lists hold 4 groups per (query, split), so the k-th
+// smallest coarse value still bounds the k-th neighbour; a full list inside the window re-scans its split, as for k <= 2)
+template <bool VEC4, int NS, bool FUSE, bool GEN, int KM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void knn_l2_refine(
     const float* __restrict__ Q, const float* __restrict__ T, const float* __restrict__ qnorm,
     const unsigned long long* __restrict__ stats, unsigned epoch, unsigned* __restrict__ diag, int nq, int nt,
@@ -723,7 +803,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void knn_
     // d2a = ||q||^2 - 2w; first of the 4 consecutive rows of the group the slot names
     float val[NS];
     int row0[NS];
-    float m0 = KNN_INF, m1 = KNN_INF;
+    MinN<float, KM> mn;
+    mn.init(KNN_INF);
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         const int s = lane + 64 * i;
@@ -740,17 +821,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void knn_
         const int tile = static_cast<int>(gid >> gshift), rem = static_cast<int>(gid & ((1u << gshift) - 1u));
         val[i] = v;
         row0[i] = (split * tiles_per_split + tile) * rows_per_tile + 32 * (rem >> 2) + 8 * (rem & 3) + 4 * hh;
-        if (v < m1) { if (v < m0) { m1 = m0; m0 = v; } else { m1 = v; } }
+        mn.insert(v);
     }
     static_assert(KNN_C == 4, "slot decoding assumes 4 entries per list");
-    // k-th smallest coarse value over all slots (k <= 2)
+    // k-th smallest coarse value over all slots (k <= KM)
     float tau = KNN_INF;
     for (int round = 0; round < k; ++round) {
-        tau = wave_min_f32(m0);
-        const unsigned long long owners = __ballot(m0 == tau);
+        tau = wave_min_f32(mn.m[0]);
+        const unsigned long long owners = __ballot(mn.m[0] == tau);
         if (owners == 0ull) break;               // NaN guard
         const int first = __ffsll(static_cast<long long>(owners)) - 1;
-        if (lane == first) { m0 = m1; m1 = KNN_INF; }
+        if (lane == first) mn.pop(KNN_INF);
     }
     const float thr = (tau + eps) * 1.00000095367431640625f + eps;
 
@@ -758,7 +839,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void knn_
     const bool rescan = nonfinite || !(thr < KNN_INF) || unranked;
     if (diag && lane == 0 && !ghost) { if (rescan) atomicAdd(&diag[0], 1u); if (nonfinite) diag[1] = 1u; }
 
-    Best2 b{~0ull, ~0ull, KNN_INF, KNN_INF};
+    BestN<KM> b;
+    b.init();
     if (!rescan) {
         const int grp = lane >> 3, l = lane & 7;
         int total = 0;
@@ -787,7 +869,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void knn_
                     if (row < nt) {
                         const float d = __builtin_sqrtf(
                             l2sqr_canonical<VEC4>(qp, T + static_cast<size_t>(row) * dim, dim));
-                        best2_insert(b, knn_key(d, row), d);
+                        b.insert(knn_key(d, row), d);
                     }
                 }
             }
@@ -806,24 +888,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void knn_
             const float d2 = l2sqr_canonical_coop8(qp, T + static_cast<size_t>(jj) * dim, dim, l);
             if (live && l == 0) {
                 const float d = __builtin_sqrtf(d2);
-                best2_insert(b, knn_key(d, jj), d);
+                b.insert(knn_key(d, jj), d);
             }
         }
     } else {
         for (int j = lane; j < nt; j += 64) {
             const float d =
                 __builtin_sqrtf(l2sqr_canonical<VEC4>(qp, T + static_cast<size_t>(j) * dim, dim));
-            best2_insert(b, knn_key(d, j), d);
+            b.insert(knn_key(d, j), d);
         }
     }
     int nn_idx[2] = {-1, -1};                                // wave-uniform copies of the first two neighbours (FUSE)
     float nn_d[2] = {KNN_INF, KNN_INF};
     for (int c = 0; c < k; ++c) {
-        const uint64_t best = wave_min_u64(b.k0);
-        const unsigned long long owners = __ballot(b.k0 == best);
+        const uint64_t best = wave_min_u64(b.k[0]);
+        const unsigned long long owners = __ballot(b.k[0] == best);
         const int first = __ffsll(static_cast<long long>(owners)) - 1;
-        const float dist = __shfl(b.d0, first, 64);
-        if (lane == first) { b.k0 = b.k1; b.d0 = b.d1; b.k1 = ~0ull; b.d1 = KNN_INF; }
+        const float dist = __shfl(b.d[0], first, 64);
+        if (lane == first) b.pop();
         pm_match m;
         m.queryIdx = q;
         m.imgIdx = 0;
@@ -959,7 +1041,7 @@ __device__ __forceinline__ unsigned long long row_min_u64(unsigned long long v)
     return (static_cast<unsigned long long>(mh) << 32) | ml;
 }
 
-template <int NS, int GROUP>
+template <int NS, int GROUP, int KM>
 __global__ __launch_bounds__(256) void knn_l2_refine8(
     const float* __restrict__ Q, const float* __restrict__ T, const uint4* __restrict__ Q8, const uint4* __restrict__ T8,
     const float* __restrict__ qnorm, const float* __restrict__ tnorm, const int* __restrict__ cand,
@@ -986,7 +1068,8 @@ __global__ __launch_bounds__(256) void knn_l2_refine8(
     // slot s = l + 16*i: candidate (w << U8_SHIFT) | (group id << 1 | lane half); coarse squared distance
     // d2a = ||q'||^2 - 2w = d2 or d2 - 1 of the group's best row
     int val[NS], code[NS];
-    int m0 = IMAX, m1 = IMAX;
+    MinN<int, KM> mn;
+    mn.init(IMAX);
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         const int s = l + 16 * i;
@@ -1000,14 +1083,14 @@ __global__ __launch_bounds__(256) void knn_l2_refine8(
         val[i] = v;
         // first row of the group's 32-row block | (group inside the block << 1) | lane half   (block rows are multiples of 32)
         code[i] = ((split * tiles_per_split + tile) * H_TT + 32 * (rem / GPB)) | ((rem % GPB) << 1) | hh;
-        if (v < m1) { if (v < m0) { m1 = m0; m0 = v; } else { m1 = v; } }
+        mn.insert(v);
     }
     static_assert(KNN_C == 4, "slot decoding assumes 4 entries per list");
     int tau = IMAX;
-    for (int round = 0; round < k; ++round) {                // k <= 2
-        tau = static_cast<int>(row_min_u32(static_cast<unsigned>(m0) ^ 0x80000000u) ^ 0x80000000u);
-        const unsigned owners = static_cast<unsigned>(__ballot(m0 == tau) >> (16 * qi)) & 0xFFFFu;
-        if (l == __ffs(static_cast<int>(owners)) - 1) { m0 = m1; m1 = IMAX; }
+    for (int round = 0; round < k; ++round) {                // k <= KM
+        tau = static_cast<int>(row_min_u32(static_cast<unsigned>(mn.m[0]) ^ 0x80000000u) ^ 0x80000000u);
+        const unsigned owners = static_cast<unsigned>(__ballot(mn.m[0] == tau) >> (16 * qi)) & 0xFFFFu;
+        if (l == __ffs(static_cast<int>(owners)) - 1) mn.pop(IMAX);
     }
     bool full = wrong_hint || tau == IMAX;                   // fewer than k ranked groups (nt < k, ...): scan everything
     const int thr = tau == IMAX ? 0 : tau + 1;
@@ -1031,11 +1114,12 @@ __global__ __launch_bounds__(256) void knn_l2_refine8(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    Best2 b{~0ull, ~0ull, KNN_INF, KNN_INF};
+    BestN<KM> b;
+    b.init();
     auto take = [&](int row) {
         const int d2 = u8_row_d2(qv, T8, row, qn, tnorm);
         const float d = __builtin_sqrtf(static_cast<float>(d2));
-        best2_insert(b, knn_key(d, row), d);
+        b.insert(knn_key(d, row), d);
     };
     const int nrows = full ? 0 : total * GROUP;
     for (int r0 = 0; __any(r0 < nrows); r0 += 16) {          // one row per lane, 16 per query and pass
@@ -1052,7 +1136,7 @@ __global__ __launch_bounds__(256) void knn_l2_refine8(
             const float* qp = Q + static_cast<size_t>(qc) * dim;
             for (int j = l; j < nt; j += 16) {
                 const float d = __builtin_sqrtf(l2sqr_canonical<true>(qp, T + static_cast<size_t>(j) * dim, dim));
-                best2_insert(b, knn_key(d, j), d);
+                b.insert(knn_key(d, j), d);
             }
         } else {
             for (int j0 = 0; j0 < nt; j0 += 16)
@@ -1060,11 +1144,11 @@ __global__ __launch_bounds__(256) void knn_l2_refine8(
         }
     }
     for (int c = 0; c < k; ++c) {
-        const uint64_t best = row_min_u64(b.k0);
-        const unsigned owners = static_cast<unsigned>(__ballot(b.k0 == best) >> (16 * qi)) & 0xFFFFu;
+        const uint64_t best = row_min_u64(b.k[0]);
+        const unsigned owners = static_cast<unsigned>(__ballot(b.k[0] == best) >> (16 * qi)) & 0xFFFFu;
         const int first = __ffs(static_cast<int>(owners)) - 1;
-        const float dist = __shfl(b.d0, 16 * qi + first, 64);
-        if (l == first) { b.k0 = b.k1; b.d0 = b.d1; b.k1 = ~0ull; b.d1 = KNN_INF; }
+        const float dist = __shfl(b.d[0], 16 * qi + first, 64);
+        if (l == first) b.pop();
         pm_match m;
         m.queryIdx = q;
         m.imgIdx = 0;
@@ -1319,23 +1403,31 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
     const bool u8in = uq != nullptr;
     if (u8in) {
         const bool al = ((reinterpret_cast<uintptr_t>(uq) | reinterpret_cast<uintptr_t>(ut)) & 3) == 0;
-        if (!(k <= 2 && (dim % 4) == 0 && dim <= 128 && nt >= 1 && al && fuse == nullptr)) return 2;
+        if (!(k <= 4 && (dim % 4) == 0 && dim <= 128 && nt >= 1 && al && fuse == nullptr)) return 2;
         flags = PM_KNN_HINT_U8;
     }
 
     // the MFMA routes read rows as 16-byte vectors: dim % 4 == 0 AND 16-byte aligned base pointers (anything else
     // takes the exact kernel, whose loads are scalar unless both hold)
+    // Rows are read as 16-byte vectors when dim % 4 == 0 and the base pointers are 16-byte aligned; the f16 passes (round 3)
+    // also take any other layout (element loads in the prep and refinement kernels: the padded copies do not care) and up
+    // to 256 dimensions (17 k-chunks).  The f32-input pass and the u8 route stay at dim % 4 == 0, dim <= 128.
     const bool aligned16 = u8in || ((reinterpret_cast<uintptr_t>(dq) | reinterpret_cast<uintptr_t>(dt)) & 15) == 0;
-    const bool fast = !(flags & PM_KNN_FORCE_EXACT) && k <= 2 && (dim % 4) == 0 && dim <= 128 && nt >= 1 && aligned16;
+    const bool vec = (dim % 4) == 0 && aligned16;
+    const bool narrow = vec && dim <= 128;
+    const bool wide16 = !narrow && !(flags & PM_KNN_FORCE_F32) && ctx->opts[PM_OPT_KNN_WIDE] != 1;
+    const bool fast = !(flags & PM_KNN_FORCE_EXACT) && (k <= 2 || (k <= 4 && ctx->opts[PM_OPT_KNN_WIDE] != 1)) && dim <= 256 &&
+                      nt >= 1 && (narrow || wide16) && (dim >= 4 || !vec);
     if (!fast) {
         const int rx = run_exact(ctx, dq, nq, dt, nt, dim, k, dout);
         return rx == PM_OK && fuse ? 1 : rx;                 // 1: done, but the caller still has to filter
     }
-    int route = (flags & PM_KNN_FORCE_F32) ? ROUTE_F32 : (flags & PM_KNN_HINT_U8) ? ROUTE_U8_HINT :
-                (flags & PM_KNN_HINT_INTEGER) ? ROUTE_F16_HINT : ROUTE_AUTO;
+    int route = (flags & PM_KNN_FORCE_F32) ? ROUTE_F32 : ((flags & PM_KNN_HINT_U8) && narrow) ? ROUTE_U8_HINT :
+                (flags & (PM_KNN_HINT_INTEGER | PM_KNN_HINT_U8)) ? ROUTE_F16_HINT : ROUTE_AUTO;
+    const int dp16 = dim <= 128 ? 128 : 256;                 // padded columns of the f16 copies
     // automatic route: general floats rank on rounded f16 copies too (SPEC S1c); the f32-input pass is enqueued only when
     // forced (PM_KNN_FORCE_F32) or when PM_OPT_KNN_GENERAL_F16 = 1 keeps it as the automatic route's pass for such data
-    const bool gen32 = route == ROUTE_AUTO && ctx->opts[PM_OPT_KNN_GENERAL_F16] == 1;
+    const bool gen32 = route == ROUTE_AUTO && ctx->opts[PM_OPT_KNN_GENERAL_F16] == 1 && narrow;
     const bool want32 = route == ROUTE_F32 || gen32, want16 = route != ROUTE_F32;
 
     // ---- f32 route geometry: 64-row tiles, 128 queries per workgroup, two workgroups per CU.
@@ -1416,7 +1508,7 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
     const bool u8_int_refine = !(ctx->opts[PM_OPT_KNN_U8_REFINE] == 1 && u8_group == 4);
     // (f16 pass: the seeded form measured SLOWER than the seed chunk — C3 21.1 vs 18.7 us, 32k x 32k 199 vs 203 us: the four
     // C-in reads per block cost what the ninth MFMA cost — so it runs only when PM_OPT_KNN_SEEDED = 2 asks for it)
-    const bool f16s = route == ROUTE_F16_HINT && seeded_opt == 2 &&
+    const bool f16s = route == ROUTE_F16_HINT && seeded_opt == 2 && narrow &&
                       (static_cast<long long>(nt_pad) + H_TT) * (F16S_ROW16 * 16) < 0x7FFFFFFFLL;
     const bool u8r = route == ROUTE_U8_HINT;
     if (u8r) {
@@ -1434,7 +1526,7 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
     // interleave calls on one context are serialised by the stream.
     const size_t c32 = want32 ? sizeof(float) * static_cast<size_t>(nq) * g32.slots : 0;
     const size_t c16 = want16 ? sizeof(float) * static_cast<size_t>(nq) * g16.slots : 0;
-    const size_t rowb = u8r ? U8_DP : sizeof(_Float16) * (f16s ? H_DP : H_ROW);   // bytes per row of the coarse copies
+    const size_t rowb = u8r ? U8_DP : sizeof(_Float16) * (f16s ? H_DP : dp16 + 16);   // bytes per row of the coarse copies
     const size_t qh = want16 ? rowb * static_cast<size_t>(nq_pad) : 0;
     const size_t th = want16 ? rowb * static_cast<size_t>(nt_pad) : 0;
     const size_t sdb = (u8r || f16s) ? 4 * static_cast<size_t>(nt_pad + H_TT) : 0;       // seeds (+ one tile of slack)
@@ -1487,19 +1579,29 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
                                nt, nt_pad, dim, qnorm, tnorm, reinterpret_cast<uint2*>(Qh), reinterpret_cast<uint2*>(Th),
                                static_cast<int*>(seeds), stats, epoch);
         else if (f16s)
-            hipLaunchKernelGGL(knn_l2_prep16<true>, dim3(nq_pad / 64 + nt_pad / 64), dim3(256), 0, ctx->stream, dq, nq, nq_pad,
-                               dt, nt, nt_pad, dim, qnorm, tnorm, Qh, Th, static_cast<float*>(seeds), stats, epoch);
-        else if (want16)
-            hipLaunchKernelGGL(knn_l2_prep16<false>, dim3(nq_pad / 64 + nt_pad / 64), dim3(256), 0, ctx->stream, dq, nq, nq_pad,
-                               dt, nt, nt_pad, dim, qnorm, tnorm, Qh, Th, nullptr, stats, epoch);
+            hipLaunchKernelGGL((knn_l2_prep16<true, 128, true>), dim3(nq_pad / 64 + nt_pad / 64), dim3(256), 0, ctx->stream, dq, nq,
+                               nq_pad, dt, nt, nt_pad, dim, qnorm, tnorm, Qh, Th, static_cast<float*>(seeds), stats, epoch);
+        else if (want16) {
+#define PM_PREP16(DP_, AL_)                                                                                               \
+    hipLaunchKernelGGL((knn_l2_prep16<false, DP_, AL_>), dim3(nq_pad / 64 + nt_pad / 64), dim3(256), 0, ctx->stream, dq, nq,    \
+                       nq_pad, dt, nt, nt_pad, dim, qnorm, tnorm, Qh, Th, nullptr, stats, epoch)
+            if (dp16 == 128) { if (vec) PM_PREP16(128, true); else PM_PREP16(128, false); }
+            else { if (vec) PM_PREP16(256, true); else PM_PREP16(256, false); }
+#undef PM_PREP16
+        }
         else
             hipLaunchKernelGGL(knn_l2_prep, dim3((nq + 63) / 64 + (nt + 63) / 64), dim3(256), 0, ctx->stream, dq, nq, dt,
                                nt, dim, qnorm, tnorm, stats, epoch);
         // automatic route: data that failed the integer premise get f16-ROUNDED scaled copies instead (the train scale
         // needs the norm maximum of the pass above, hence a launch of its own; it returns at once for integer data)
-        if (route == ROUTE_AUTO && !gen32)
-            hipLaunchKernelGGL(knn_l2_prep16g, dim3(nq_pad / 64 + nt_pad / 64), dim3(256), 0, ctx->stream, dq, nq, nq_pad, dt,
-                               nt, nt_pad, dim, qnorm, tnorm, Qh, Th, stats, epoch);
+        if (route == ROUTE_AUTO && !gen32) {
+#define PM_PREP16G(DP_, AL_)                                                                                              \
+    hipLaunchKernelGGL((knn_l2_prep16g<DP_, AL_>), dim3(nq_pad / 64 + nt_pad / 64), dim3(256), 0, ctx->stream, dq, nq, nq_pad, dt, \
+                       nt, nt_pad, dim, qnorm, tnorm, Qh, Th, stats, epoch)
+            if (dp16 == 128) { if (vec) PM_PREP16G(128, true); else PM_PREP16G(128, false); }
+            else { if (vec) PM_PREP16G(256, true); else PM_PREP16G(256, false); }
+#undef PM_PREP16G
+        }
         else if (gen32)
             hipLaunchKernelGGL(knn_gen_off, dim3(1), dim3(64), 0, ctx->stream, stats, epoch);
         PM_HIP_CHECK(hipGetLastError());
@@ -1514,7 +1616,7 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
         if (rc != PM_OK) return rc;
     } else if (want16) {
         rc = launch_coarse_f16(ctx, Qh, Th, nq, nq_pad, nt, splits16, g16.tiles_per_split, ~g16.lid_mask, cval16,
-                               g16.slots, stats, epoch, route == ROUTE_AUTO ? 1 : 0);
+                               g16.slots, stats, epoch, route == ROUTE_AUTO ? 1 : 0, dp16);
         if (rc != PM_OK) return rc;
     }
     if (want32) {
@@ -1524,10 +1626,11 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
     }
     if (u8r && u8_int_refine) {
         pm::ScopedKernelTime t(ctx, "knn_l2_refine");
-#define PM_R8(NS_, GROUP_)                                                                                                 \
-    hipLaunchKernelGGL((knn_l2_refine8<NS_, GROUP_>), dim3((nq + 15) / 16), dim3(256), 0, ctx->stream, dq, dt,              \
+#define PM_R8K(NS_, GROUP_, KM_)                                                                                           \
+    hipLaunchKernelGGL((knn_l2_refine8<NS_, GROUP_, KM_>), dim3((nq + 15) / 16), dim3(256), 0, ctx->stream, dq, dt,         \
                        reinterpret_cast<const uint4*>(Qh), reinterpret_cast<const uint4*>(Th), qnorm, tnorm,               \
                        reinterpret_cast<const int*>(cval16), stats, epoch, diag, nq, nt, dim, k, g16.slots, g16.tiles_per_split, dout)
+#define PM_R8(NS_, GROUP_) do { if (k <= 2) PM_R8K(NS_, GROUP_, 2); else PM_R8K(NS_, GROUP_, 4); } while (0)
 #define PM_R8G(NS_) do { if (u8_group == 4) PM_R8(NS_, 4); else if (u8_group == 8) PM_R8(NS_, 8); else PM_R8(NS_, 16); } while (0)
         if (g16.slots <= 16) PM_R8G(1);                      // slots of a query per lane of its 16-lane row
         else if (g16.slots <= 32) PM_R8G(2);
@@ -1536,21 +1639,26 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
         else PM_R8G(16);
 #undef PM_R8G
 #undef PM_R8
+#undef PM_R8K
         PM_HIP_CHECK(hipGetLastError());
         return PM_OK;
     }
     {
         pm::ScopedKernelTime t(ctx, "knn_l2_refine");
         const int max_slots = (want16 ? g16.slots : 0) > (want32 ? g32.slots : 0) ? g16.slots : g32.slots;
-#define PM_REFINE3(NS_, FUSE_, GEN_)                                                                                 \
-    hipLaunchKernelGGL((knn_l2_refine<true, NS_, FUSE_, GEN_>), dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, dq, dt,  \
+#define PM_REFINE5(VEC_, NS_, FUSE_, GEN_, KM_)                                                                      \
+    hipLaunchKernelGGL((knn_l2_refine<VEC_, NS_, FUSE_, GEN_, KM_>), dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, dq, dt,  \
                        qnorm, stats, epoch, diag, nq, nt, dim, k, g16, g32, route, dout, fz)
+#define PM_REFINE4(VEC_, NS_, FUSE_, GEN_) do { if (k <= 2) PM_REFINE5(VEC_, NS_, FUSE_, GEN_, 2); else PM_REFINE5(VEC_, NS_, false, GEN_, 4); } while (0)
+#define PM_REFINE3(NS_, FUSE_, GEN_) do { if (vec) PM_REFINE4(true, NS_, FUSE_, GEN_); else PM_REFINE4(false, NS_, FUSE_, GEN_); } while (0)
 #define PM_REFINE2(NS_, FUSE_) do { if (route == ROUTE_AUTO) PM_REFINE3(NS_, FUSE_, true); else PM_REFINE3(NS_, FUSE_, false); } while (0)
 #define PM_REFINE(NS_) do { if (fuse) PM_REFINE2(NS_, true); else PM_REFINE2(NS_, false); } while (0)
         if (max_slots <= 64) PM_REFINE(1);
         else if (max_slots <= 128) PM_REFINE(2);
         else if (max_slots <= 256) PM_REFINE(4);
         else PM_REFINE(8);
+#undef PM_REFINE5
+#undef PM_REFINE4
 #undef PM_REFINE3
 #undef PM_REFINE2
 #undef PM_REFINE

@@ -84,9 +84,10 @@ int launch_coarse_f32(pm_ctx* ctx, const float* dq, int nq, const float* dt, int
                       int splits, int tiles_per_split, unsigned keep_mask, float* cval, int slots,
                       const unsigned long long* stats, unsigned epoch, int only_if_ineligible);
 // Enqueue the exact f16-MFMA coarse pass on the padded f16 copies.  mode 1: run only if eligible.
+// dp: padded data columns of the copies, 128 or 256.
 int launch_coarse_f16(pm_ctx* ctx, const _Float16* Qh, const _Float16* Th, int nq, int nq_pad, int nt, int splits,
                       int tiles_per_split, unsigned keep_mask, float* cval, int slots,
-                      const unsigned long long* stats, unsigned epoch, int mode);
+                      const unsigned long long* stats, unsigned epoch, int mode, int dp = 128);
 
 // Enqueue the i8-MFMA coarse pass of the Hamming matcher on the expanded +-1 copies.  A candidate
 // is (dot << I8_SHIFT) | group id, dot = 256 - 2*hamming.

@@ -40,11 +40,13 @@ def time_knn(nq, nt, dim, k, flags, reps=5):
             "pairs_per_s": nq * nt / (ms * 1e-3), "valu_tflops": 3.0 * dim * nq * nt / (ms * 1e-3) / 1e12}
 
 
-for (nq, nt, dim, k, flags, what) in [(8192, 8192, 128, 2, 0, "general floats, automatic route (f32-input MFMA)"),
-                                      (8192, 8192, 128, 2, pm.api.PM_KNN_FORCE_EXACT, "exact kernel forced"),
-                                      (8192, 8192, 128, 3, 0, "k = 3 -> exact kernel"),
-                                      (8192, 8192, 130, 2, 0, "dim % 4 != 0 -> exact kernel"),
-                                      (8192, 8192, 256, 2, 0, "dim > 128 -> exact kernel"),
+for (nq, nt, dim, k, flags, what) in [(8192, 8192, 128, 2, 0, "general floats, automatic route (f16 matrix pass on rounded copies)"),
+                                      (8192, 8192, 128, 2, pm.api.PM_KNN_FORCE_EXACT, "exact VALU kernel forced"),
+                                      (8192, 8192, 128, 3, 0, "k = 3 (round 3: matrix pass + 4-deep refinement; round 2: exact kernel)"),
+                                      (8192, 8192, 128, 4, 0, "k = 4"),
+                                      (8192, 8192, 130, 2, 0, "dim % 4 != 0 (round 3: f16 pass on 256-column padded copies, element loads)"),
+                                      (8192, 8192, 256, 2, 0, "dim 256 (round 3: 17 k-chunks)"),
+                                      (8192, 8192, 200, 3, 0, "dim 200, k = 3"),
                                       (8192, 8192, 64, 2, 0, "dim 64 (SURF-64), automatic route")]:
     r = time_knn(nq, nt, dim, k, flags)
     r["what"] = what
