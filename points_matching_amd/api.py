@@ -681,6 +681,9 @@ class FlannIndex:
         _check(lib().pm_flann_knn_l2_f32(self._ctx._h, self._h, _p(q), q.shape[0], k, _p(out)))
         return out
 
+    def knn_dev(self, dq_ptr, nq, k, dout_ptr):
+        _check(lib().pm_flann_knn_l2_f32_dev(self._ctx._h, self._h, C.c_void_p(dq_ptr), nq, k, C.c_void_p(dout_ptr)))
+
     def export(self):
         """(nodes structured array, roots int32[trees])"""
         n = C.c_int32()

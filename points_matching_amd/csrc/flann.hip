@@ -168,25 +168,65 @@ struct FlSearch {
     int trees;
     const float* T;
     int nt, dim, k, checks;
-    float* heap_d;                    // [FL_HEAP_CAP][nq_pad]
-    int* heap_n;
-    unsigned* checked;                // [words][nq_pad]
+    unsigned* checked;                // [nq_pad][words]: examined-point bit set of every query
     int nq_pad, words;
 };
 
-// One lane per query.  Heap entry e of query q lives at [e * nq_pad + q].
-__global__ __launch_bounds__(64) void flann_search(FlSearch s, const float* __restrict__ Q, int nq, pm_match* __restrict__ out)
+// SPEC S1 by 8 consecutive lanes (lane l = accumulator l of the canonical form, canonical combine): one row costs one
+// memory round trip instead of dim/8 dependent ones.  Valid in every lane of the wave (the 8 partial sums are broadcast).
+__device__ __forceinline__ float fl_l2sqr_coop(const float* __restrict__ a, const float* __restrict__ b, int dim, int lane)
 {
-    const int q = blockIdx.x * 64 + threadIdx.x;
-    if (q >= nq) return;
+    const int l = lane & 7;
+    float acc = 0.f;
+    const int full8 = dim & ~7;
+    for (int j0 = 0; j0 < full8; j0 += 64) {                 // up to 8 column groups' loads in flight together
+        float av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = j0 + 8 * u + l;
+            const int cc = c < full8 ? c : l;                // (clamped: the load stays unconditional)
+            av[u] = a[cc]; bv[u] = b[cc];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (j0 + 8 * u < full8) { const float t = av[u] - bv[u]; const float p = t * t; acc = acc + p; }
+    }
+    float e[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) e[i] = __shfl(acc, i, 64);   // accumulator i (lanes 0..7 hold them)
+    const float s0 = e[0] + e[4], s1 = e[1] + e[5], s2 = e[2] + e[6], s3 = e[3] + e[7];
+    float d = ((s0 + s1) + s2) + s3;
+    for (int j = full8; j < dim; ++j) {
+        const float t = a[j] - b[j];
+        const float p = t * t;
+        d = d + p;
+    }
+    return d;
+}
+
+// ONE WAVE PER QUERY (round 3; round 2: one lane per query — 300 queries were five waves on the whole chip, each lane
+// chasing its own pointers: 1.3 ms).  The best-bin-first search is a dependent chain by nature; here every value of the
+// chain is wave-uniform, so the branches cost nothing, the heap lives in LDS (lane 0 writes, every lane reads the same
+// word), the row distances are evaluated by 8 lanes in the canonical order, and 300 queries are 300 waves on 256 CUs.
+// Same visiting order and same bits as pmo_flann_search (tests/test_flann_gpu.py).
+constexpr int FL_QPW = 4;             // queries (waves) per workgroup
+__global__ __launch_bounds__(64 * FL_QPW) void flann_search(FlSearch s, const float* __restrict__ Q, int nq, pm_match* __restrict__ out)
+{
+    __shared__ float hd[FL_QPW][FL_HEAP_CAP];
+    __shared__ int hn[FL_QPW][FL_HEAP_CAP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = __builtin_amdgcn_readfirstlane(blockIdx.x * FL_QPW + wave);
+    if (q >= nq) return;                                       // wave-uniform; no workgroup barriers below
+    float* heap_d = hd[wave];
+    int* heap_n = hn[wave];
     const float* qv = Q + static_cast<size_t>(q) * s.dim;
+    unsigned* chk = s.checked + static_cast<size_t>(q) * s.words;
     float rd[FL_MAX_K];                                        // result set, ascending squared distances
     int ri[FL_MAX_K];
 #pragma unroll
     for (int i = 0; i < FL_MAX_K; ++i) { rd[i] = __builtin_inff(); ri[i] = -1; }
     int rcount = 0, hcount = 0, check_count = 0;
-    const size_t st = static_cast<size_t>(s.nq_pad);
-    for (int w = 0; w < s.words; ++w) s.checked[w * st + q] = 0u;
+    for (int w = 0; w < s.words; ++w) chk[w] = 0u;           // (every lane, same words: see the leaf test below)
 
     auto worst = [&]() -> float {
         float v = rd[0];
@@ -197,47 +237,44 @@ __global__ __launch_bounds__(64) void flann_search(FlSearch s, const float* __re
     // binary min-heap on (bound, node id): the id breaks ties between equal bounds, so the order in which branches are
     // taken up is a property of the forest and the query, not of a heap implementation (SPEC S17)
     auto before = [](float da, int na, float db, int nb) -> bool { return da < db || (da == db && na < nb); };
+    auto put = [&](int i, float d, int n) { if (lane == 0) { heap_d[i] = d; heap_n[i] = n; } };
     auto heap_push = [&](float d, int node) {
         if (hcount >= FL_HEAP_CAP) return;                      // FLANN's Heap::insert also drops when full
         int i = hcount++;
         while (i > 0) {                                         // sift up
             const int p = (i - 1) >> 1;
-            const float pd = s.heap_d[p * st + q];
-            const int pn = s.heap_n[p * st + q];
+            const float pd = heap_d[p];
+            const int pn = heap_n[p];
             if (!before(d, node, pd, pn)) break;
-            s.heap_d[i * st + q] = pd;
-            s.heap_n[i * st + q] = pn;
+            put(i, pd, pn);
             i = p;
         }
-        s.heap_d[i * st + q] = d;
-        s.heap_n[i * st + q] = node;
+        put(i, d, node);
     };
     auto heap_pop = [&](float& d, int& node) -> bool {
         if (hcount == 0) return false;
-        d = s.heap_d[q];
-        node = s.heap_n[q];
+        d = heap_d[0];
+        node = heap_n[0];
         --hcount;
         if (hcount > 0) {
-            const float ld = s.heap_d[hcount * st + q];
-            const int ln = s.heap_n[hcount * st + q];
+            const float ld = heap_d[hcount];
+            const int ln = heap_n[hcount];
             int i = 0;
             for (;;) {                                          // sift down
                 int c = 2 * i + 1;
                 if (c >= hcount) break;
-                float cd = s.heap_d[c * st + q];
-                int cn = s.heap_n[c * st + q];
+                float cd = heap_d[c];
+                int cn = heap_n[c];
                 if (c + 1 < hcount) {
-                    const float cd2 = s.heap_d[(c + 1) * st + q];
-                    const int cn2 = s.heap_n[(c + 1) * st + q];
+                    const float cd2 = heap_d[c + 1];
+                    const int cn2 = heap_n[c + 1];
                     if (before(cd2, cn2, cd, cn)) { cd = cd2; cn = cn2; ++c; }
                 }
                 if (!before(cd, cn, ld, ln)) break;
-                s.heap_d[i * st + q] = cd;
-                s.heap_n[i * st + q] = cn;
+                put(i, cd, cn);
                 i = c;
             }
-            s.heap_d[i * st + q] = ld;
-            s.heap_n[i * st + q] = ln;
+            put(i, ld, ln);
         }
         return true;
     };
@@ -249,11 +286,11 @@ __global__ __launch_bounds__(64) void flann_search(FlSearch s, const float* __re
             if (nd.child1 < 0) {                                // leaf
                 const int idx = nd.divfeat;
                 const unsigned bit = 1u << (idx & 31);
-                const unsigned wv = s.checked[(idx >> 5) * st + q];
+                const unsigned wv = chk[idx >> 5];
                 if ((wv & bit) || (check_count >= s.checks && rcount >= s.k)) return;
-                s.checked[(idx >> 5) * st + q] = wv | bit;
+                chk[idx >> 5] = wv | bit;                    // every lane stores the same word: each later reads its own store
                 ++check_count;
-                const float d = fl_l2sqr(qv, s.T + static_cast<size_t>(idx) * s.dim, s.dim);
+                const float d = fl_l2sqr_coop(qv, s.T + static_cast<size_t>(idx) * s.dim, s.dim, lane);
                 // KNNResultSet::addPoint: insert in ascending order (an equal distance goes behind the earlier one)
                 if (rcount < s.k || d < worst()) {
                     float cd = d;
@@ -295,7 +332,7 @@ __global__ __launch_bounds__(64) void flann_search(FlSearch s, const float* __re
         for (int i = 1; i < FL_MAX_K; ++i) { if (i == c) { d = rd[i]; id = ri[i]; } }
         m.trainIdx = id;
         m.distance = id >= 0 ? __builtin_sqrtf(d) : __builtin_inff();
-        out[static_cast<size_t>(q) * s.k + c] = m;
+        if (lane == 0) out[static_cast<size_t>(q) * s.k + c] = m;
     }
 }
 
@@ -310,8 +347,6 @@ struct pm_flann_index {
     FlNode* d_nodes = nullptr;
     float* d_train = nullptr;
     // per-call scratch, grow-only
-    float* d_heap_d = nullptr;
-    int* d_heap_n = nullptr;
     unsigned* d_checked = nullptr;
     int scratch_nq = 0;
 };
@@ -321,7 +356,7 @@ extern "C" int pm_flann_destroy(pm_flann_index* ix)
     if (!ix) return PM_OK;
     (void)hipSetDevice(ix->device);
     (void)hipFree(ix->d_nodes); (void)hipFree(ix->d_train);
-    (void)hipFree(ix->d_heap_d); (void)hipFree(ix->d_heap_n); (void)hipFree(ix->d_checked);
+    (void)hipFree(ix->d_checked);
     delete ix;
     return PM_OK;
 }
@@ -380,10 +415,8 @@ extern "C" int pm_flann_knn_l2_f32_dev(pm_ctx* ctx, pm_flann_index* ix, const fl
     const int words = (ix->nt + 31) / 32;
     if (nq_pad > ix->scratch_nq) {
         PM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        (void)hipFree(ix->d_heap_d); (void)hipFree(ix->d_heap_n); (void)hipFree(ix->d_checked);
-        ix->d_heap_d = nullptr; ix->d_heap_n = nullptr; ix->d_checked = nullptr; ix->scratch_nq = 0;
-        PM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ix->d_heap_d), sizeof(float) * FL_HEAP_CAP * static_cast<size_t>(nq_pad)));
-        PM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ix->d_heap_n), sizeof(int) * FL_HEAP_CAP * static_cast<size_t>(nq_pad)));
+        (void)hipFree(ix->d_checked);
+        ix->d_checked = nullptr; ix->scratch_nq = 0;
         PM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ix->d_checked), sizeof(unsigned) * static_cast<size_t>(words) * nq_pad));
         ix->scratch_nq = nq_pad;
     }
@@ -391,10 +424,10 @@ extern "C" int pm_flann_knn_l2_f32_dev(pm_ctx* ctx, pm_flann_index* ix, const fl
     s.nodes = ix->d_nodes;
     for (int t = 0; t < ix->trees; ++t) s.roots[t] = ix->roots[t];
     s.trees = ix->trees; s.T = ix->d_train; s.nt = ix->nt; s.dim = ix->dim; s.k = k; s.checks = ix->checks;
-    s.heap_d = ix->d_heap_d; s.heap_n = ix->d_heap_n; s.checked = ix->d_checked;
+    s.checked = ix->d_checked;
     s.nq_pad = ix->scratch_nq; s.words = words;
     pm::ScopedKernelTime t(ctx, "flann_search");
-    hipLaunchKernelGGL(flann_search, dim3(nq_pad / 64), dim3(64), 0, ctx->stream, s, d_q, nq, d_out);
+    hipLaunchKernelGGL(flann_search, dim3((nq + FL_QPW - 1) / FL_QPW), dim3(64 * FL_QPW), 0, ctx->stream, s, d_q, nq, d_out);
     PM_HIP_CHECK(hipGetLastError());
     return PM_OK;
 }
