@@ -112,7 +112,8 @@ enum {
     PM_OPT_KNN_RING_PROLOGUE = 14, /* u8 ring kernel: train tiles requested before the sweep starts, 2 .. 8 (default 2)    */
     PM_OPT_KNN_WIDE       = 15, /* L2 matcher beyond dim % 4 == 0 && dim <= 128 && 16-byte aligned rows: 1 = exact VALU kernel (round 2),
                                    2 = f16 matrix passes on padded copies, up to 256 dimensions (default)             */
-    PM_OPT_COUNT_         = 16
+    PM_OPT_KNN_PREP_ROWS  = 16, /* u8 route, prep kernel: 1 = 64 rows per workgroup, 2 = 16 rows per workgroup (default)         */
+    PM_OPT_COUNT_         = 17
 };
 int  pm_ctx_set_option(pm_ctx* ctx, int option, int value);
 int  pm_ctx_get_option(pm_ctx* ctx, int option, int* value);

@@ -79,6 +79,7 @@ PM_OPT_KNN_RING = 12
 PM_OPT_KNN_U8_REFINE = 13
 PM_OPT_KNN_RING_PROLOGUE = 14
 PM_OPT_KNN_WIDE = 15
+PM_OPT_KNN_PREP_ROWS = 16
 
 
 _lib = None

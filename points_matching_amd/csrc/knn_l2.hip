@@ -29,6 +29,10 @@ namespace {
 using namespace pm_knn;
 
 constexpr int TILE_T = 64;    // train rows per LDS tile of the exact kernel
+// u8 route: ratio test + compaction + gather inside the refinement launch?  Measured SLOWER than the separate filter launch at
+// every size (matcher stage, us: C2 19.3 vs 17.7, C3 28.0 vs 27.0, 32k x 32k 143.5 vs 137.9): a kernel boundary costs less than
+// the in-launch look-back behind the slowest workgroup.  The fused form stays selectable (PM_OPT_FILTER_FUSION = 2).
+constexpr bool PM_U8_FUSED_BY_DEFAULT = false;
 constexpr float KNN_INF = __builtin_inff();
 
 __device__ __forceinline__ uint32_t f32_bits(float f) { return __float_as_uint(f); }
@@ -319,6 +323,7 @@ __global__ __launch_bounds__(256) void knn_l2_prep16(const float* __restrict__ Q
 // the seeds, and VERIFIES the premise (integers in [0, 255]); a wrong hint raises bit 1 of stats[1] and the refinement
 // re-scans exactly, as on the f16 hint route.
 // ---------------------------------------------------------------------------------------------
+template <int ITERS>
 __global__ __launch_bounds__(256) void knn_l2_prep8(const float* __restrict__ Q, int nq, int nq_pad,
                                                     const float* __restrict__ T, int nt, int nt_pad, int dim,
                                                     float* __restrict__ qnorm, float* __restrict__ tnorm,
@@ -328,17 +333,17 @@ __global__ __launch_bounds__(256) void knn_l2_prep8(const float* __restrict__ Q,
 {
     __shared__ unsigned wbad[4];
     const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    const int qblocks = nq_pad / 64;
+    const int qblocks = nq_pad / (16 * ITERS);
     const bool is_t = static_cast<int>(blockIdx.x) >= qblocks;
     const float* x = is_t ? T : Q;
     const int n = is_t ? nt : nq;
     uint2* x8 = is_t ? T8 : Q8;
-    const int row0 = (is_t ? blockIdx.x - qblocks : blockIdx.x) * 64;
+    const int row0 = (is_t ? blockIdx.x - qblocks : blockIdx.x) * (16 * ITERS);
     unsigned bad = 0u;
     const int c0 = 8 * sub;
-    f32x4 ld[4][2];
+    f32x4 ld[ITERS][2];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {                          // all eight loads of a thread in flight together (see prep16)
+    for (int it = 0; it < ITERS; ++it) {                      // all the loads of a thread in flight together (see prep16)
         const int row = row0 + it * 16 + grp;
         const float* p = x + static_cast<size_t>(row < n ? row : n - 1) * dim;
 #pragma unroll
@@ -348,7 +353,7 @@ __global__ __launch_bounds__(256) void knn_l2_prep8(const float* __restrict__ Q,
         }
     }
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < ITERS; ++it) {
         const int row = row0 + it * 16 + grp;                 // < n_pad by construction
         const bool live = row < n;
         float s = 0.f;
@@ -1041,12 +1046,16 @@ __device__ __forceinline__ unsigned long long row_min_u64(unsigned long long v)
     return (static_cast<unsigned long long>(mh) << 32) | ml;
 }
 
-template <int NS, int GROUP, int KM>
+// FUSE (k == 2): the ratio test, the stable compaction and the keypoint gather (main.cpp:49-69 in its ratio form, :77-78,
+// :89-91) ride this launch.  A workgroup holds 16 whole queries, so nothing is handed between workgroups but ONE
+// epoch-tagged survivor count each (decoupled look-back over the earlier workgroups, as in filter_ratio_gather); `out`
+// may then be null.
+template <int NS, int GROUP, int KM, bool FUSE>
 __global__ __launch_bounds__(256) void knn_l2_refine8(
     const float* __restrict__ Q, const float* __restrict__ T, const uint4* __restrict__ Q8, const uint4* __restrict__ T8,
     const float* __restrict__ qnorm, const float* __restrict__ tnorm, const int* __restrict__ cand,
     const unsigned long long* __restrict__ stats, unsigned epoch, unsigned* __restrict__ diag, int nq, int nt, int dim, int k,
-    int slots, int tiles_per_split, pm_match* __restrict__ out)
+    int slots, int tiles_per_split, pm_match* __restrict__ out, KnnFuse fz)
 {
     constexpr int GPB = 16 / GROUP;                          // groups per 32-row block and lane half
     constexpr int IMAX = 0x7FFFFFFF;
@@ -1143,6 +1152,8 @@ __global__ __launch_bounds__(256) void knn_l2_refine8(
                 if (full && j0 + l < nt) take(j0 + l);
         }
     }
+    int nn_idx[2] = {-1, -1};                                // the first two neighbours of the row's query (FUSE)
+    float nn_d[2] = {KNN_INF, KNN_INF};
     for (int c = 0; c < k; ++c) {
         const uint64_t best = row_min_u64(b.k[0]);
         const unsigned owners = static_cast<unsigned>(__ballot(b.k[0] == best) >> (16 * qi)) & 0xFFFFu;
@@ -1154,7 +1165,63 @@ __global__ __launch_bounds__(256) void knn_l2_refine8(
         m.imgIdx = 0;
         if (best == ~0ull) { m.trainIdx = -1; m.distance = KNN_INF; }
         else { m.trainIdx = static_cast<int>(static_cast<uint32_t>(best)); m.distance = dist; }
-        if (l == 0 && live) out[static_cast<size_t>(q) * k + c] = m;
+        if (c < 2) { nn_idx[c] = m.trainIdx; nn_d[c] = m.distance; }
+        if (l == 0 && live && out) out[static_cast<size_t>(q) * k + c] = m;
+    }
+    if constexpr (FUSE) {
+        __shared__ unsigned s_bits[4];
+        __shared__ unsigned long long s_rec[16];
+        __shared__ int s_pre[4];
+        const int tid = threadIdx.x;
+        const float rhs = fz.ratio * nn_d[1];                // pm_filter_ratio: float multiply, strict <
+        const bool keep = live && nn_idx[0] >= 0 && nn_idx[1] >= 0 && nn_d[0] < rhs;
+        if (l == 0)
+            s_rec[wave * 4 + qi] = (static_cast<unsigned long long>(f32_bits(nn_d[0])) << 32) |
+                                   static_cast<unsigned long long>(static_cast<uint32_t>(nn_idx[0]));
+        const unsigned long long bal = __ballot(l == 0 && keep);
+        if (lane == 0)
+            s_bits[wave] = static_cast<unsigned>(bal & 1ull) | (static_cast<unsigned>((bal >> 16) & 1ull) << 1) |
+                           (static_cast<unsigned>((bal >> 32) & 1ull) << 2) | (static_cast<unsigned>((bal >> 48) & 1ull) << 3);
+        __syncthreads();
+        const unsigned bits = s_bits[0] | (s_bits[1] << 4) | (s_bits[2] << 8) | (s_bits[3] << 12);
+        const int cnt = __popc(bits);
+        const int blk = static_cast<int>(blockIdx.x);
+        if (tid == 0)
+            __hip_atomic_store(&fz.tilecnt[blk], (fz.epoch << 8) | static_cast<unsigned>(cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int before = 0;
+        for (int j = tid; j < blk; j += 256) {               // earlier workgroups were dispatched earlier: bounded spin anyway
+            unsigned v = 0u, spins = 0u;
+            for (;;) {
+                v = __hip_atomic_load(&fz.tilecnt[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((v >> 8) == fz.epoch || ++spins > KF_SPIN_LIMIT) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if ((v >> 8) == fz.epoch) before += static_cast<int>(v & 255u);
+            else __hip_atomic_store(fz.err, fz.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+        if (lane == 0) s_pre[wave] = before;
+        __syncthreads();
+        const int prefix = s_pre[0] + s_pre[1] + s_pre[2] + s_pre[3];
+        if (tid < 16 && ((bits >> tid) & 1u)) {
+            const int qg = blk * 16 + tid;
+            const int off = prefix + __popc(bits & ((1u << tid) - 1u));
+            const unsigned long long rec = s_rec[tid];
+            pm_match m;
+            m.queryIdx = qg;
+            m.trainIdx = static_cast<int>(static_cast<uint32_t>(rec));
+            m.imgIdx = 0;
+            m.distance = __uint_as_float(static_cast<uint32_t>(rec >> 32));
+            fz.good[off] = m;
+            if (fz.kp1) {
+                *reinterpret_cast<float2*>(fz.xy1 + 2 * static_cast<size_t>(off)) =
+                    *reinterpret_cast<const float2*>(fz.kp1 + 2 * static_cast<size_t>(qg));
+                *reinterpret_cast<float2*>(fz.xy2 + 2 * static_cast<size_t>(off)) =
+                    *reinterpret_cast<const float2*>(fz.kp2 + 2 * static_cast<size_t>(m.trainIdx));
+            }
+        }
+        if (blk == static_cast<int>(gridDim.x) - 1 && tid == 0) *fz.n_out = prefix + cnt;
     }
 }
 
@@ -1368,9 +1435,9 @@ int run_exact(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt, int
 
 
 // per-context words of the fused compaction: arrival word + epoch-tagged survivor count per 32-query tile
-int kf_prepare(pm_ctx* ctx, int nq, KnnFuse& fz)
+int kf_prepare(pm_ctx* ctx, int nq, KnnFuse& fz, int queries_per_tile = 32)
 {
-    const int tiles = (nq + 31) / 32;
+    const int tiles = (nq + queries_per_tile - 1) / queries_per_tile;
     if (tiles > ctx->kf_cap) {
         PM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         if (ctx->kf_tile) PM_HIP_CHECK(hipFree(ctx->kf_tile));
@@ -1403,7 +1470,7 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
     const bool u8in = uq != nullptr;
     if (u8in) {
         const bool al = ((reinterpret_cast<uintptr_t>(uq) | reinterpret_cast<uintptr_t>(ut)) & 3) == 0;
-        if (!(k <= 4 && (dim % 4) == 0 && dim <= 128 && nt >= 1 && al && fuse == nullptr)) return 2;
+        if (!(k <= 4 && (dim % 4) == 0 && dim <= 128 && nt >= 1 && al)) return 2;
         flags = PM_KNN_HINT_U8;
     }
 
@@ -1495,9 +1562,8 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
     // the seeded forms (round 3) of the two hint routes: LDS-DMA staging only, and the u8 route's integer candidates
     // leave 9 bits for the id (<= 2048 train rows per split, which the split rule above keeps below 64 splits)
     const int seeded_opt = ctx->opts[PM_OPT_KNN_SEEDED];
-    // (the u8 route's integer refinement writes k-NN records: the fused filter-in-refinement form stays on the f16 pass)
     if (route == ROUTE_U8_HINT && (lid_bits16 > U8_SHIFT || (static_cast<long long>(nt_pad) + H_TT) * U8_DP >= 0x7FFFFFFFLL ||
-                                   seeded_opt == 1 || fuse != nullptr))
+                                   seeded_opt == 1))
     {
         if (u8in) return 2;                                     // (u8 rows: the caller widens and takes the f32 entry point)
         route = ROUTE_F16_HINT;                                 // u8-valued data satisfy the integer premise too
@@ -1551,7 +1617,7 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
         fz = *fuse;
         fz.pk = static_cast<unsigned long long*>(pm::arena_take(ctx, pkb));
         PM_REQUIRE(fz.pk != nullptr, PM_E_NOMEM, "scratch arena too small");
-        rc = kf_prepare(ctx, nq, fz);
+        rc = kf_prepare(ctx, nq, fz, (u8r && u8_int_refine) ? 16 : 32);      // (refine8: one count per 16-query workgroup)
         if (rc != PM_OK) return rc;
     }
     g32.cand = cval32;
@@ -1574,8 +1640,12 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
             hipLaunchKernelGGL(knn_l2_prep8_u8, dim3(nq_pad / 64 + nt_pad / 64), dim3(256), 0, ctx->stream, uq, nq, nq_pad, ut, nt,
                                nt_pad, dim, qnorm, tnorm, reinterpret_cast<uint2*>(Qh), reinterpret_cast<uint2*>(Th),
                                static_cast<int*>(seeds));
+        else if (u8r && ctx->opts[PM_OPT_KNN_PREP_ROWS] != 1)      // 16 rows per workgroup: matcher call 23.5 -> 22.2 us at C3, 15.1 -> 14.2 at C2
+            hipLaunchKernelGGL(knn_l2_prep8<1>, dim3(nq_pad / 16 + nt_pad / 16), dim3(256), 0, ctx->stream, dq, nq, nq_pad, dt,
+                               nt, nt_pad, dim, qnorm, tnorm, reinterpret_cast<uint2*>(Qh), reinterpret_cast<uint2*>(Th),
+                               static_cast<int*>(seeds), stats, epoch);
         else if (u8r)
-            hipLaunchKernelGGL(knn_l2_prep8, dim3(nq_pad / 64 + nt_pad / 64), dim3(256), 0, ctx->stream, dq, nq, nq_pad, dt,
+            hipLaunchKernelGGL(knn_l2_prep8<4>, dim3(nq_pad / 64 + nt_pad / 64), dim3(256), 0, ctx->stream, dq, nq, nq_pad, dt,
                                nt, nt_pad, dim, qnorm, tnorm, reinterpret_cast<uint2*>(Qh), reinterpret_cast<uint2*>(Th),
                                static_cast<int*>(seeds), stats, epoch);
         else if (f16s)
@@ -1626,11 +1696,11 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
     }
     if (u8r && u8_int_refine) {
         pm::ScopedKernelTime t(ctx, "knn_l2_refine");
-#define PM_R8K(NS_, GROUP_, KM_)                                                                                           \
-    hipLaunchKernelGGL((knn_l2_refine8<NS_, GROUP_, KM_>), dim3((nq + 15) / 16), dim3(256), 0, ctx->stream, dq, dt,         \
+#define PM_R8K(NS_, GROUP_, KM_, FUSE_)                                                                                    \
+    hipLaunchKernelGGL((knn_l2_refine8<NS_, GROUP_, KM_, FUSE_>), dim3((nq + 15) / 16), dim3(256), 0, ctx->stream, dq, dt,  \
                        reinterpret_cast<const uint4*>(Qh), reinterpret_cast<const uint4*>(Th), qnorm, tnorm,               \
-                       reinterpret_cast<const int*>(cval16), stats, epoch, diag, nq, nt, dim, k, g16.slots, g16.tiles_per_split, dout)
-#define PM_R8(NS_, GROUP_) do { if (k <= 2) PM_R8K(NS_, GROUP_, 2); else PM_R8K(NS_, GROUP_, 4); } while (0)
+                       reinterpret_cast<const int*>(cval16), stats, epoch, diag, nq, nt, dim, k, g16.slots, g16.tiles_per_split, dout, fz)
+#define PM_R8(NS_, GROUP_) do { if (fuse) PM_R8K(NS_, GROUP_, 2, true); else if (k <= 2) PM_R8K(NS_, GROUP_, 2, false); else PM_R8K(NS_, GROUP_, 4, false); } while (0)
 #define PM_R8G(NS_) do { if (u8_group == 4) PM_R8(NS_, 4); else if (u8_group == 8) PM_R8(NS_, 8); else PM_R8(NS_, 16); } while (0)
         if (g16.slots <= 16) PM_R8G(1);                      // slots of a query per lane of its 16-lane row
         else if (g16.slots <= 32) PM_R8G(2);
@@ -1706,8 +1776,11 @@ extern "C" int pm_bf_knn_l2_ratio_dev(pm_ctx* ctx, const float* d_q, int nq, con
     // in-launch hand-off (write-through store, drain, arrival atomic, look-back, dependent loads) costs about what the
     // launch boundary it replaces costs, and it lengthens every workgroup.  So the two-launch form is the default
     // whenever the caller provides the record buffer; PM_OPT_FILTER_FUSION = 2 selects the fused launch, 1 the two launches.
+    // u8 route (PM_KNN_HINT_U8): its refinement holds 16 whole queries per workgroup, so the fused tail is one count per
+    // workgroup and a look-back — PM_OPT_FILTER_FUSION = 0 takes the form that measured faster there.
     const int fusion = ctx->opts[PM_OPT_FILTER_FUSION];
-    const bool separate = fusion == 1 || (fusion == 0 && d_knn != nullptr);
+    const bool u8_hint = (flags & PM_KNN_HINT_U8) && !(flags & (PM_KNN_FORCE_F32 | PM_KNN_FORCE_EXACT));
+    const bool separate = fusion == 1 || (fusion == 0 && d_knn != nullptr && !(u8_hint && PM_U8_FUSED_BY_DEFAULT));
     int rc;
     if (!separate) {
         rc = knn_l2_enqueue(ctx, d_q, nq, d_t, nt, dim, 2, flags, d_knn, &fz);
@@ -1777,6 +1850,13 @@ extern "C" int pm_bf_knn_l2_u8_ratio_dev(pm_ctx* ctx, const uint8_t* d_q, int nq
     if (nq == 0) {
         PM_HIP_CHECK(hipMemsetAsync(d_n_good, 0, sizeof(int32_t), ctx->stream));
         return PM_OK;
+    }
+    const int fusion = ctx->opts[PM_OPT_FILTER_FUSION];
+    if (fusion == 2 || (fusion == 0 && PM_U8_FUSED_BY_DEFAULT)) {
+        KnnFuse fz{};
+        fz.ratio = ratio; fz.kp1 = d_kp1_xy; fz.kp2 = d_kp2_xy; fz.good = d_good; fz.xy1 = d_xy1; fz.xy2 = d_xy2; fz.n_out = d_n_good;
+        const int rf = nt >= 1 ? knn_l2_enqueue(ctx, nullptr, nq, nullptr, nt, dim, 2, 0, d_knn, &fz, d_q, d_t) : 2;
+        if (rf != 2) return rf;                              // done (fused) or failed; 2: a shape for the widened f32 path
     }
     const int rc = pm_bf_knn_l2_u8_dev(ctx, d_q, nq, d_t, nt, dim, 2, d_knn);
     if (rc != PM_OK) return rc;
