@@ -113,7 +113,9 @@ enum {
     PM_OPT_KNN_WIDE       = 15, /* L2 matcher beyond dim % 4 == 0 && dim <= 128 && 16-byte aligned rows: 1 = exact VALU kernel (round 2),
                                    2 = f16 matrix passes on padded copies, up to 256 dimensions (default)             */
     PM_OPT_KNN_PREP_ROWS  = 16, /* u8 route, prep kernel: 1 = 64 rows per workgroup, 2 = 16 rows per workgroup (default)         */
-    PM_OPT_COUNT_         = 17
+    PM_OPT_RANSAC_FORM    = 17, /* one-launch RANSAC kernel: 1 = correspondences in registers, two teams of four waves (round 2),
+                                   2 = correspondences in LDS, one wave per hypothesis, 12 waves (default)           */
+    PM_OPT_COUNT_         = 18
 };
 int  pm_ctx_set_option(pm_ctx* ctx, int option, int value);
 int  pm_ctx_get_option(pm_ctx* ctx, int option, int* value);

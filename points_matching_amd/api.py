@@ -80,6 +80,7 @@ PM_OPT_KNN_U8_REFINE = 13
 PM_OPT_KNN_RING_PROLOGUE = 14
 PM_OPT_KNN_WIDE = 15
 PM_OPT_KNN_PREP_ROWS = 16
+PM_OPT_RANSAC_FORM = 17
 
 
 _lib = None

@@ -460,6 +460,231 @@ __global__ __launch_bounds__(RF_WG) void ransac_fused(pm_points_view v, uint64_t
     DIAG::phase(9);
 }
 
+// ---- round 3: the same one-launch run with the correspondences in LDS and ONE WAVE PER HYPOTHESIS -------------------------
+// Stamps of the register-tile kernel above (profiles/r02_ransac_phase_stamps.txt, r03_ransac_stamps_vs_ids_per_workgroup.txt):
+// the fp64 solve is a ~21k-cycle stream per wave WHATEVER its lane count (40, 20, 10, 5 or 1 ids per workgroup: 20.9k-22.4k), the
+// two teams then need 18.3k + 13.5k cycles for 40 hypotheses at two waves per SIMD (~6 cycles per instruction, four partial
+// counts per hypothesis to combine, the second team trailing the first), and the tile load waits for the solve.  Here
+//   * the tile lives in LDS as packed pairs (x_a x_b | y_a y_b | x'_a x'_b | y'_a y'_b per lane and 128-point slot: 2 KiB per
+//     slot, config C3's 2275 correspondences = 36 KiB), loaded by the waves that do not solve WHILE the solver waves solve;
+//   * 12 waves = 3 per SIMD (768 threads: the 156-VGPR solver still fits without spills) each score WHOLE hypotheses
+//     (wave w: ids w, w + 12, ...): operands by ds_read_b64, model in SGPR pairs as before, the inlier count of a hypothesis
+//     is a scalar sum of s_bcnt1 in ONE wave — no partial counts, no team skew;
+//   * key, slot, ticket, winner and mask as above (the last workgroup reads the mask's operands from LDS again).
+// Same operations on the same values: keys, masks and models are bit-identical to the register-tile kernel and the oracle.
+constexpr int RL_WAVES = 12;
+constexpr int RL_THREADS = RL_WAVES * 64;
+constexpr int RL_SLOT_PTS = 128;             // points per slot: 64 lanes x 2 (packed)
+constexpr int RL_MAX_SLOTS = 64;             // slots per LDS tile: 128 KiB dynamic (+ ~18 KiB static) of the CU's 160 KiB
+
+template <int KIND, typename DIAG>
+__global__ __launch_bounds__(RL_THREADS) void ransac_fused_lds(pm_points_view v, uint64_t seed, int64_t hyp_begin, int nh, int hb,
+                                                               float thr2, int tile_slots, RfSlot* __restrict__ slots,
+                                                               int* __restrict__ ticket, RfOut out)
+{
+    extern __shared__ __attribute__((aligned(16))) f32x2 s_pts[];           // [tile_slots][4][64]: X, Y, XP, YP pairs
+    __shared__ __attribute__((aligned(16))) float s_mdl[RF_HB_MAX][12];    // f32 model + valid flag of hypothesis s
+    __shared__ double s_m64[RF_HB_MAX][9];
+    __shared__ int s_cnt[RF_HB_MAX];
+    __shared__ int s_offs[PM_MAX_PARTS + 1];
+    __shared__ unsigned long long s_wk[RL_WAVES];
+    __shared__ double s_F64[9];
+    __shared__ int s_role;
+    __shared__ int s_wc[RL_WAVES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    DIAG::phase(0);
+    int n;
+    if (v.parts == 1) {
+        n = view_count1(v);
+    } else {
+        view_offsets(v, s_offs, tid);
+        __syncthreads();
+        n = s_offs[v.parts];
+    }
+    DIAG::phase(1);
+    const int tile_pts = tile_slots * RL_SLOT_PTS;
+    const int ntiles = n > tile_pts ? (n + tile_pts - 1) / tile_pts : 1;
+    const float nanv = __builtin_nanf("");
+    // slot `slot`, lane `l` of the tile that starts at point `base`: points base + 2*(64*slot + l) and +1 (NaN past n)
+    auto load_pair = [&](int base, int slot, int l) {
+        const int i0 = base + 2 * (64 * slot + l);
+        float2 a0 = {nanv, nanv}, b0 = a0, a1 = a0, b1 = a0;
+        if (v.parts == 1) {
+            if (n > 0) {
+                const int j0 = i0 < n ? i0 : n - 1, j1 = i0 + 1 < n ? i0 + 1 : n - 1;      // unconditional clamped loads
+                a0 = *reinterpret_cast<const float2*>(v.xy1 + 2 * static_cast<size_t>(j0));
+                a1 = *reinterpret_cast<const float2*>(v.xy1 + 2 * static_cast<size_t>(j1));
+                b0 = *reinterpret_cast<const float2*>(v.xy2 + 2 * static_cast<size_t>(j0));
+                b1 = *reinterpret_cast<const float2*>(v.xy2 + 2 * static_cast<size_t>(j1));
+            }
+            if (i0 >= n) { a0 = float2{nanv, nanv}; b0 = a0; }
+            if (i0 + 1 >= n) { a1 = float2{nanv, nanv}; b1 = a1; }
+        } else {
+            if (i0 < n) view_point(v, s_offs, i0, a0, b0);
+            if (i0 + 1 < n) view_point(v, s_offs, i0 + 1, a1, b1);
+        }
+        f32x2* d = s_pts + (static_cast<size_t>(slot) * 4) * 64 + l;
+        d[0] = f32x2{a0.x, a1.x}; d[64] = f32x2{a0.y, a1.y}; d[128] = f32x2{b0.x, b1.x}; d[192] = f32x2{b0.y, b1.y};
+    };
+    auto tile_kslots = [&](int t) {
+        int k = (n - t * tile_pts + RL_SLOT_PTS - 1) / RL_SLOT_PTS;
+        return k < 0 ? 0 : (k > tile_slots ? tile_slots : k);
+    };
+
+    // ---- solve (threads < hcount: SPEC S6, S7) || tile 0 -> LDS (the other waves)
+    const int h0 = static_cast<int>(blockIdx.x) * hb;
+    const int hcount = nh - h0 < hb ? nh - h0 : hb;
+    const int solver_waves = (hcount + 63) / 64;                            // 1 (or 2 beyond 64 ids per workgroup)
+    DIAG::phase(2);
+    if (wave < solver_waves) {
+        if (tid < hcount) {
+            double F[9];
+            bool ok = false;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) F[i] = 0.0;
+            if (n >= 8) ok = hyp_model_view<DIAG>(v, s_offs, n, seed, static_cast<uint64_t>(hyp_begin + h0 + tid), F);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) { s_mdl[tid][i] = static_cast<float>(F[i]); s_m64[tid][i] = F[i]; }
+            s_mdl[tid][9] = ok ? 1.f : 0.f;
+            s_mdl[tid][10] = 0.f; s_mdl[tid][11] = 0.f;
+            s_cnt[tid] = 0;
+        }
+    } else {
+        const int k0 = tile_kslots(0);
+        for (int slot = wave - solver_waves; slot < k0; slot += RL_WAVES - solver_waves) load_pair(0, slot, lane);
+    }
+    DIAG::phase(3);
+    __syncthreads();
+    DIAG::phase(4);
+
+    // ---- score: wave w takes whole hypotheses w, w + 12, ...; the count of a hypothesis is a scalar sum in one wave
+    for (int t = 0; t < ntiles; ++t) {
+        const int kslots = tile_kslots(t);
+        if (t > 0) {
+            __syncthreads();                                               // everyone is done with the previous tile
+            for (int slot = wave; slot < kslots; slot += RL_WAVES) load_pair(t * tile_pts, slot, lane);
+            __syncthreads();
+        }
+        for (int s = wave; s < hcount; s += RL_WAVES) {
+            const f32x4v c0 = *reinterpret_cast<const f32x4v*>(&s_mdl[s][0]);
+            const f32x4v c1 = *reinterpret_cast<const f32x4v*>(&s_mdl[s][4]);
+            const f32x2 c2 = *reinterpret_cast<const f32x2*>(&s_mdl[s][8]);
+            const ModelS ms = model_to_sgprs(c0, c1, c2);
+            int c = 0;
+            const f32x2* pp = s_pts + lane;
+#pragma unroll 2
+            for (int slot = 0; slot < kslots; ++slot) {
+                const f32x2 x = pp[0], y = pp[64], xp = pp[128], yp = pp[192];
+                pp += 256;
+                bool ia, ib;
+                inlier_pk_model<KIND>(ms, x, y, xp, yp, thr2, ia, ib);
+                c += __popcll(__ballot(ia)) + __popcll(__ballot(ib));
+            }
+            if (lane == 0) s_cnt[s] += c;                                  // (this wave owns hypothesis s: no other writer)
+        }
+    }
+    DIAG::phase(5);
+    __syncthreads();
+
+    // ---- the workgroup's best key (SPEC S9: most inliers, then lowest id) and its slot
+    unsigned long long key = 0ull;
+    if (tid < hcount && s_mdl[tid][9] != 0.f)
+        key = (static_cast<unsigned long long>(static_cast<uint32_t>(s_cnt[tid])) << 32) |
+              static_cast<unsigned long long>(0xFFFFFFFFu - static_cast<uint32_t>(hyp_begin + h0 + tid));
+    const unsigned long long kbest = wg_max_u64<RL_WAVES>(key, s_wk, tid);
+    if (wave == 0) {
+        const int sb = kbest ? static_cast<int>(static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(kbest)) - hyp_begin) - h0 : 0;
+        RfSlot* sl = slots + blockIdx.x;
+        if (lane < 9) __hip_atomic_store(&sl->F[lane], kbest ? s_m64[sb][lane] : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 9) __hip_atomic_store(&sl->key, kbest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the slot is written through before the ticket is drawn
+        if (lane == 0) {
+            const int tk = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_role = tk == static_cast<int>(gridDim.x) - 1 ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    DIAG::phase(6);
+    if (s_role == 0) { DIAG::phase(9); return; }
+
+    // ---- last workgroup: every slot is complete.  Winner = max key over the slots.
+    if (tid == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    unsigned long long kb = 0ull;
+    double fb[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) fb[i] = 0.0;
+    for (int j = tid; j < static_cast<int>(gridDim.x); j += RL_THREADS) {
+        const unsigned long long kj = __hip_atomic_load(&slots[j].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double fj[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) fj[i] = __hip_atomic_load(&slots[j].F[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (kj > kb) {
+            kb = kj;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) fb[i] = fj[i];
+        }
+    }
+    const unsigned long long kwin = wg_max_u64<RL_WAVES>(kb, s_wk, tid);
+    const bool ok = kwin != 0ull && n >= 8;
+    if (tid < 9) s_F64[tid] = 0.0;
+    __syncthreads();
+    if (ok && kb == kwin) {                                  // exactly one thread: keys of distinct ids differ
+#pragma unroll
+        for (int i = 0; i < 9; ++i) s_F64[i] = fb[i];
+    }
+    __syncthreads();
+    DIAG::phase(7);
+    if (out.shard) {
+        if (tid < 9) out.rec->F[tid] = s_F64[tid];
+        if (tid == 9) out.rec->key = ok ? kwin : 0ull;
+        return;
+    }
+    if (tid < 9) {
+        if (out.F) out.F[tid] = s_F64[tid];
+        if (out.fo) { out.fo->F[tid] = s_F64[tid]; out.fo->F32[tid] = static_cast<float>(s_F64[tid]); }
+    }
+    if (tid == 9) {
+        *out.key = ok ? kwin : 0ull;
+        if (out.fo) out.fo->valid = ok ? 1 : 0;
+    }
+    float fw[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) fw[i] = static_cast<float>(s_F64[i]);
+    int mine = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        const int kslots = tile_kslots(t);
+        if (ntiles > 1) {                                    // (a single tile is still in LDS)
+            __syncthreads();
+            for (int slot = wave; slot < kslots; slot += RL_WAVES) load_pair(t * tile_pts, slot, lane);
+            __syncthreads();
+        }
+        for (int slot = wave; slot < kslots; slot += RL_WAVES) {
+            const f32x2* pp = s_pts + static_cast<size_t>(slot) * 256 + lane;
+            bool ia, ib;
+            inlier32_x2_flags<KIND>(fw, pp[0], pp[64], pp[128], pp[192], thr2, ia, ib);
+            ia = ia && ok; ib = ib && ok;
+            const int i0 = t * tile_pts + 2 * (64 * slot + lane);
+            if (i0 < out.mask_len) out.mask[i0] = ia ? 1 : 0;
+            if (i0 + 1 < out.mask_len) out.mask[i0 + 1] = ib ? 1 : 0;
+            mine += __popcll(__ballot(ia)) + __popcll(__ballot(ib));     // wave-uniform
+        }
+    }
+    if (lane == 0) s_wc[wave] = mine;
+    const int covered = n > 0 ? (n + RL_SLOT_PTS - 1) / RL_SLOT_PTS * RL_SLOT_PTS : 0;
+    for (int i = covered + tid; i < out.mask_len; i += RL_THREADS) out.mask[i] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < RL_WAVES; ++w) tot += s_wc[w];
+        if (out.n_inliers) *out.n_inliers = tot;
+        if (out.fo) out.fo->n_inliers = tot;
+    }
+    DIAG::phase(8);
+    DIAG::phase(9);
+}
+
 int check_view(const pm_points_view* v)
 {
     PM_REQUIRE(v != nullptr && v->xy1 && v->xy2, PM_E_INVALID, "null correspondence view");
@@ -506,6 +731,30 @@ int fused_launch_t(pm_ctx* ctx, const pm_points_view& v, const pm_ransac_params*
     if (fo_out) *fo_out = fo;
     const float thr2 = p->thresh_px * p->thresh_px;
     pm::ScopedKernelTime t(ctx, "ransac_fused");
+    // PM_OPT_RANSAC_FORM: 1 = correspondences in registers, two teams (round 2), 2 = correspondences in LDS, one wave per
+    // hypothesis (round 3, the default)
+    if (ctx->opts[PM_OPT_RANSAC_FORM] != 1) {
+        long long need = (cap_total + RL_SLOT_PTS - 1) / RL_SLOT_PTS;
+        const int tile_slots = static_cast<int>(need < 1 ? 1 : (need > RL_MAX_SLOTS ? RL_MAX_SLOTS : need));
+        const size_t lds = static_cast<size_t>(tile_slots) * 4 * 64 * sizeof(f32x2);
+        static bool attr_done_dev[PM_MAX_DEVICES] = {};
+        if (!attr_done_dev[ctx->device]) {
+            const int lmax = RL_MAX_SLOTS * 4 * 64 * static_cast<int>(sizeof(f32x2));
+            PM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ransac_fused_lds<PM_ERR_SAMPSON, DIAG>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, lmax));
+            PM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ransac_fused_lds<PM_ERR_SYM_EPIPOLAR, DIAG>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, lmax));
+            attr_done_dev[ctx->device] = true;
+        }
+        if (p->error_kind == PM_ERR_SAMPSON)
+            hipLaunchKernelGGL((ransac_fused_lds<PM_ERR_SAMPSON, DIAG>), dim3(nwg), dim3(RL_THREADS), lds, ctx->stream, v, p->seed,
+                               p->hyp_begin, static_cast<int>(nh), hb, thr2, tile_slots, slots, sync, out);
+        else
+            hipLaunchKernelGGL((ransac_fused_lds<PM_ERR_SYM_EPIPOLAR, DIAG>), dim3(nwg), dim3(RL_THREADS), lds, ctx->stream, v, p->seed,
+                               p->hyp_begin, static_cast<int>(nh), hb, thr2, tile_slots, slots, sync, out);
+        PM_HIP_CHECK(hipGetLastError());
+        return PM_OK;
+    }
     // 2*RF_PPT2 points per thread: a 2560-point tile (config C3 fits one); small capacities take the 2-slot build
 #define PM_RF(KIND_, PPT2_)                                                                                              \
     hipLaunchKernelGGL((ransac_fused<KIND_, PPT2_, DIAG>), dim3(nwg), dim3(RF_WG), 0, ctx->stream, v, p->seed, p->hyp_begin, \

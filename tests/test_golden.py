@@ -20,7 +20,7 @@ def _knn_cases():
 
 
 def test_fixtures_present():
-    assert len(glob.glob(os.path.join(GOLD, "*.npz"))) == 10
+    assert len(glob.glob(os.path.join(GOLD, "*.npz"))) == 11
 
 
 @pytest.mark.parametrize("name,k", _knn_cases())

@@ -47,7 +47,9 @@ def test_sharded_run_over_a_view_equals_the_oracle(ctx, oracle, counts, cap, kin
     view = _view(g1, g2, gn, cap)
     recs = torch.zeros(shards * 10, dtype=torch.float64, device=dev)        # 80-byte records
     for r in range(shards):
+        ctx.set_option(pm.api.PM_OPT_RANSAC_FORM, 1 if r == 1 else 0)       # (the middle shard on the round-2 register form)
         ctx.ransac_shard_parts_dev(view, r * H // shards, (r + 1) * H // shards, thr, seed, recs.data_ptr() + 80 * r, kind)
+    ctx.set_option(pm.api.PM_OPT_RANSAC_FORM, 0)
     mask_len = len(counts) * cap + 5
     d_key = torch.zeros(1, dtype=torch.int64, device=dev)
     d_F = torch.zeros(9, dtype=torch.float64, device=dev)
@@ -90,8 +92,9 @@ def test_device_resident_local_run_with_a_device_count(ctx, oracle, n, cap, H):
     d_F = torch.ones(9, dtype=torch.float64, device=dev)
     d_mask = torch.full((cap,), 9, dtype=torch.uint8, device=dev)
     d_ninl = torch.full((1,), -1, dtype=torch.int32, device=dev)
-    for path in (2, 1):
+    for path, form in ((2, 2), (2, 1), (1, 0)):   # one-launch kernel: LDS form (default), register form; per-lane kernels
         ctx.set_option(pm.api.PM_OPT_RANSAC_PATH, path)
+        ctx.set_option(pm.api.PM_OPT_RANSAC_FORM, form)
         try:
             for _ in range(2):          # twice: the arrival ticket must be back at zero after a launch
                 ctx.ransac_run_dev(d1.data_ptr(), d2.data_ptr(), cap, dn.data_ptr(), 0, H, 1.0, 0x5EED, d_key.data_ptr(),
@@ -99,6 +102,7 @@ def test_device_resident_local_run_with_a_device_count(ctx, oracle, n, cap, H):
             ctx.synchronize()
         finally:
             ctx.set_option(pm.api.PM_OPT_RANSAC_PATH, 0)
+            ctx.set_option(pm.api.PM_OPT_RANSAC_FORM, 0)
         rc, F_o, mask_o, ninl_o, key_o = oracle.ransac_fundamental(x1, x2, H, 1.0, 0x5EED, nthreads=8)
         m = d_mask.cpu().numpy()
         assert int(d_key.cpu().numpy().view(np.uint64)[0]) == key_o, path

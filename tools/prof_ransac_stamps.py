@@ -29,6 +29,8 @@ d_mask = torch.zeros(cap, dtype=torch.uint8, device=dev)
 d_ninl = torch.zeros(1, dtype=torch.int32, device=dev)
 ctx = pm.Context(0)
 ctx.timing_enable(True)
+if os.environ.get("PM_RANSAC_FORM"):
+    ctx.set_option(pm.api.PM_OPT_RANSAC_FORM, int(os.environ["PM_RANSAC_FORM"]))
 for _ in range(20):
     ctx.ransac_run_dev(d1.data_ptr(), d2.data_ptr(), cap, dn.data_ptr(), 0, H, 1.0, 0x5EED, d_key.data_ptr(),
                        d_F.data_ptr(), d_mask.data_ptr(), d_ninl.data_ptr())
