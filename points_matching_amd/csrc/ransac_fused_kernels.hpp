@@ -477,6 +477,36 @@ constexpr int RL_THREADS = RL_WAVES * 64;
 constexpr int RL_SLOT_PTS = 128;             // points per slot: 64 lanes x 2 (packed)
 constexpr int RL_MAX_SLOTS = 64;             // slots per LDS tile: 128 KiB dynamic (+ ~18 KiB static) of the CU's 160 KiB
 
+// NH hypotheses of one wave (ids s0, s0 + RL_WAVES, ...) over the slots of the LDS tile in ONE pass: each operand read serves NH
+// models (the LDS port, 4 x 512 B per wave and slot, would otherwise be ~3/4 as busy as the VALU and the two contend).
+template <int KIND, int NH>
+__device__ __forceinline__ void score_lds(const float (*s_mdl)[12], int* s_cnt, const f32x2* pp, int kslots, int s0, float thr2, int lane)
+{
+    ModelS ms[NH];
+    int c[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        const float* m = s_mdl[s0 + h * RL_WAVES];
+        ms[h] = model_to_sgprs(*reinterpret_cast<const f32x4v*>(m), *reinterpret_cast<const f32x4v*>(m + 4),
+                               *reinterpret_cast<const f32x2*>(m + 8));
+        c[h] = 0;
+    }
+    for (int slot = 0; slot < kslots; ++slot) {
+        const f32x2 x = pp[0], y = pp[64], xp = pp[128], yp = pp[192];
+        pp += 256;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            bool ia, ib;
+            inlier_pk_model<KIND>(ms[h], x, y, xp, yp, thr2, ia, ib);
+            c[h] += __popcll(__ballot(ia)) + __popcll(__ballot(ib));
+        }
+    }
+    if (lane == 0) {                                                       // (this wave owns these hypotheses: no other writer)
+#pragma unroll
+        for (int h = 0; h < NH; ++h) s_cnt[s0 + h * RL_WAVES] += c[h];
+    }
+}
+
 template <int KIND, typename DIAG>
 __global__ __launch_bounds__(RL_THREADS) void ransac_fused_lds(pm_points_view v, uint64_t seed, int64_t hyp_begin, int nh, int hb,
                                                                float thr2, int tile_slots, RfSlot* __restrict__ slots,
@@ -566,22 +596,12 @@ __global__ __launch_bounds__(RL_THREADS) void ransac_fused_lds(pm_points_view v,
             for (int slot = wave; slot < kslots; slot += RL_WAVES) load_pair(t * tile_pts, slot, lane);
             __syncthreads();
         }
-        for (int s = wave; s < hcount; s += RL_WAVES) {
-            const f32x4v c0 = *reinterpret_cast<const f32x4v*>(&s_mdl[s][0]);
-            const f32x4v c1 = *reinterpret_cast<const f32x4v*>(&s_mdl[s][4]);
-            const f32x2 c2 = *reinterpret_cast<const f32x2*>(&s_mdl[s][8]);
-            const ModelS ms = model_to_sgprs(c0, c1, c2);
-            int c = 0;
-            const f32x2* pp = s_pts + lane;
-#pragma unroll 2
-            for (int slot = 0; slot < kslots; ++slot) {
-                const f32x2 x = pp[0], y = pp[64], xp = pp[128], yp = pp[192];
-                pp += 256;
-                bool ia, ib;
-                inlier_pk_model<KIND>(ms, x, y, xp, yp, thr2, ia, ib);
-                c += __popcll(__ballot(ia)) + __popcll(__ballot(ib));
-            }
-            if (lane == 0) s_cnt[s] += c;                                  // (this wave owns hypothesis s: no other writer)
+        for (int s = wave; s < hcount; s += 4 * RL_WAVES) {
+            const int left = (hcount - s + RL_WAVES - 1) / RL_WAVES;       // hypotheses of this wave from s on
+            if (left >= 4) score_lds<KIND, 4>(s_mdl, s_cnt, s_pts + lane, kslots, s, thr2, lane);
+            else if (left == 3) score_lds<KIND, 3>(s_mdl, s_cnt, s_pts + lane, kslots, s, thr2, lane);
+            else if (left == 2) score_lds<KIND, 2>(s_mdl, s_cnt, s_pts + lane, kslots, s, thr2, lane);
+            else score_lds<KIND, 1>(s_mdl, s_cnt, s_pts + lane, kslots, s, thr2, lane);
         }
     }
     DIAG::phase(5);
@@ -595,9 +615,10 @@ __global__ __launch_bounds__(RL_THREADS) void ransac_fused_lds(pm_points_view v,
     const unsigned long long kbest = wg_max_u64<RL_WAVES>(key, s_wk, tid);
     if (wave == 0) {
         const int sb = kbest ? static_cast<int>(static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(kbest)) - hyp_begin) - h0 : 0;
-        RfSlot* sl = slots + blockIdx.x;
-        if (lane < 9) __hip_atomic_store(&sl->F[lane], kbest ? s_m64[sb][lane] : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (lane == 9) __hip_atomic_store(&sl->key, kbest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // slots as ten arrays of gridDim.x words (F[0] .. F[8], key): the last workgroup's scan reads them coalesced
+        double* sf = reinterpret_cast<double*>(slots) + static_cast<size_t>(lane) * gridDim.x + blockIdx.x;
+        if (lane < 9) __hip_atomic_store(sf, kbest ? s_m64[sb][lane] : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 9) __hip_atomic_store(reinterpret_cast<unsigned long long*>(sf), kbest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the slot is written through before the ticket is drawn
         if (lane == 0) {
             const int tk = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -615,10 +636,12 @@ __global__ __launch_bounds__(RL_THREADS) void ransac_fused_lds(pm_points_view v,
 #pragma unroll
     for (int i = 0; i < 9; ++i) fb[i] = 0.0;
     for (int j = tid; j < static_cast<int>(gridDim.x); j += RL_THREADS) {
-        const unsigned long long kj = __hip_atomic_load(&slots[j].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double* sf = reinterpret_cast<const double*>(slots) + j;
+        const unsigned long long kj = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(sf + 9 * static_cast<size_t>(gridDim.x)),
+                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         double fj[9];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) fj[i] = __hip_atomic_load(&slots[j].F[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < 9; ++i) fj[i] = __hip_atomic_load(sf + i * static_cast<size_t>(gridDim.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (kj > kb) {
             kb = kj;
 #pragma unroll
