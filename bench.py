@@ -53,7 +53,7 @@ def pmc_traffic(key, nq, nt):
     runs, gfx950 correction applied) and is used ONLY when that file is stamped with the hash of the kernel sources
     it was measured on and this is exactly the profiled workload; otherwise null."""
     try:
-        doc = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+        doc = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
         t = doc["kernels"]
         if doc.get("kernel_source_sha16") != _kernel_source_sha():
             return None

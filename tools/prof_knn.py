@@ -16,7 +16,7 @@ nt = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 dim = int(sys.argv[3]) if len(sys.argv) > 3 else 128
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 kind = sys.argv[5] if len(sys.argv) > 5 else "sift"
-flags = int(sys.argv[6]) if len(sys.argv) > 6 else (4 if kind == "sift" else 0)
+flags = int(sys.argv[6]) if len(sys.argv) > 6 else (8 if kind == "sift" else 0)      # 8 = PM_KNN_HINT_U8: the bench's route
 w = synth.pair_workload(nq, nt, dim, seed=0xC3, kind=kind)
 dev = torch.device("cuda", 0)
 s = torch.cuda.Stream(device=dev)
@@ -35,4 +35,4 @@ for _ in range(reps):
     ctx.bf_knn_l2_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, 2, d_out.data_ptr(), flags)
 torch.cuda.synchronize()
 print("done", nq, nt, dim, reps, kind, flags, os.environ.get("PM_LIB_PATH", "default"),
-      {k: round(ctx.timing_get(k)[0] * 1e3, 1) for k in ("knn_l2_prep", "knn_l2_mfma_f16", "knn_l2_mfma", "knn_l2_refine")})
+      {k: round(ctx.timing_get(k)[0] * 1e3, 1) for k in ("knn_l2_prep", "knn_l2_mfma_u8", "knn_l2_mfma_f16", "knn_l2_mfma", "knn_l2_refine")})
