@@ -15,9 +15,10 @@ N GPUs (weak scaling, one process per GPU): rank r matches its own 8k query rows
 blocks (RCCL, in place) -> pm_ransac_shard_parts_dev: the rank's shard of the 10k hypothesis ids over ALL gathered
 correspondences, one 80-byte (key, F) record -> all-gather #2 of the records (the arg-max all-reduce with its payload) ->
 pm_ransac_finish_parts_dev: every rank takes the record with the largest key and writes F + the inlier mask (nobody
-re-solves, nothing is broadcast).  The N > 1 step is software-pipelined: pair i+1's matcher is enqueued on a second stream
-while pair i sits in its two all-gathers and RANSAC (`--pipeline 0` runs the pairs strictly one after the other); every
-collective is also timed by itself (`collectives`).
+re-solves, nothing is broadcast).  The N > 1 step exists in two forms: software-pipelined (pair i+1's matcher is enqueued on
+a second stream while pair i sits in its two all-gathers and RANSAC) and serial (pairs strictly one after the other); a
+trial in the warm-up picks the form whose slowest rank is faster (`step_form_trial`; `--pipeline 0/1` pins one), both are
+reported (`ms_per_step_serial`, `ms_per_step_pipelined`), and every collective is also timed by itself (`collectives`).
 
 `value` = descriptor-pair distances/s of the matching stage (N*M*ranks / match-stage time);
 the RANSAC half of the metric is reported next to it (`ransac.hyp_per_s`, with N_m).
@@ -160,8 +161,10 @@ def bench_c5(args, world, rank, local_rank, dev, multi, saved_stdout):
         "metric": "descriptor-pair distances/s (BF-L2 2-NN + ratio stage); RANSAC hypotheses/s in `ransac`",
         "value": pairs_per_s * n * n, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32",
-        "dtype_note": "f32 in/out; coarse pass f16xf16->f32 MFMA (exact for u8-valued data), refinement f32",
+        "dtype": "u8" if args.c5_desc == "u8" else "f32",
+        "dtype_note": ("u8 rows in (pm_batch_set_desc_type), f32 distances out" if args.c5_desc == "u8" else "f32 in/out") +
+                      "; coarse pass i8 x i8 -> i32 MFMA on x - 128 (exact for u8-valued data, device-verified), integer "
+                      "refinement on the same bytes, distances = canonical f32 bits",
         "data": "synthetic",
         "config": {"workload": "C5: batch of %d image pairs x (%d x %d SIFT-128 %s BF-L2 2-NN + ratio 0.8 + %d-hypothesis "
                                "RANSAC-F), end to end incl. H2D/D2H from pinned host memory, %d lanes per GPU, %s; pairs "
@@ -439,6 +442,18 @@ def main():
     for i in range(args.warmup):
         step()
         step_pipe(i)
+    # Which of the two step forms the timed region reports is decided HERE, in the warm-up, not after the fact: with
+    # --pipeline -1 (default) and more than one rank (or --exercise-exchange) both forms run a trial of the same length
+    # and every rank takes the form whose slowest rank was faster (the pipelined form depends on the host keeping two
+    # streams fed; on some boxes the serial form wins).
+    form_trial = None
+    if multi and args.pipeline < 0:
+        n_trial = max(20, args.warmup)
+        tr = torch.tensor([timed(lambda i: step(), n_trial), timed(step_pipe, n_trial)], dtype=torch.float64, device=dev)
+        dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+        pipelined = bool(tr[1].item() < tr[0].item())
+        form_trial = {"steps": n_trial, "serial_ms_per_step": tr[0].item() / n_trial * 1e3,
+                      "pipelined_ms_per_step": tr[1].item() / n_trial * 1e3}
     wall_serial = timed(lambda i: step(), args.steps)
     wall_pipe = timed(step_pipe, args.steps)
     for i in range(args.steps):
@@ -707,6 +722,12 @@ def main():
                    "best_hyp": pm.api.ransac_key_hyp(key) if key else None},
         "kernels_us": kern, "knn_refine": kstats, "parity": parity,
     }
+    if form_trial:
+        out["step_form_trial"] = form_trial
+    if args.single_device and world > 1:
+        out["config"]["timing_note"] = ("%d processes share ONE GPU (--single-device): the device time-slices between processes at "
+                                        "millisecond granularity and event brackets include the other process's slices; this line "
+                                        "demonstrates parity of the N > 1 path, its timings are not performance data" % world)
     if collectives:
         out["collectives"] = collectives
     if not both:
