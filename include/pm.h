@@ -106,7 +106,11 @@ enum {
     PM_OPT_KNN_U8_GROUP   = 11, /* u8 route: rows per coarse candidate group, 1 = 4, 2 = 8 (default), 3 = 16                 */
     PM_OPT_KNN_RING       = 12, /* u8 coarse kernel, train tiles: 1 = two LDS buffers (default), 2 = ring of eight with counted
                                    waits and a workgroup barrier per tile, 3 = the ring with split-phase LDS counters
-                                   (2, 3: 8-row groups only; measured, not faster: DESIGN.md 2.1)                    */
+                                   (2, 3: 8-row groups only; measured, not faster: DESIGN.md 2.1); register-operand forms
+                                   (8-row groups only): a wave keeps 128 queries as B operands and takes 32-row blocks of
+                                   train rows by itself, no tile is shared between waves: 4 = blocks straight from global
+                                   memory, 5 = through a private LDS buffer per wave (LDS-DMA), 6 = 5 with one train split
+                                   per WAVE (no merge, no barrier; long sweeps only, else form 1 runs)               */
     PM_OPT_KNN_U8_REFINE  = 13, /* u8 route refinement: 1 = canonical f32 kernel (4-row groups only), 2 = integer
                                    re-evaluation on the byte copies, one lane per row (default)                     */
     PM_OPT_KNN_RING_PROLOGUE = 14, /* u8 ring kernel: train tiles requested before the sweep starts, 2 .. 8 (default 2)    */

@@ -9,6 +9,8 @@
 // Built with -ffinite-math-only (see knn_shared.hpp).  Nothing in this file decides a result bit:
 // the coarse values only nominate candidate rows for the canonical refinement.
 #pragma once
+#include <type_traits>
+
 #include "knn_shared.hpp"
 
 namespace pm_knn {
@@ -1206,13 +1208,376 @@ int launch_ring(pm_ctx* ctx, const char* name, const void* Qh, const void* Th, c
     return PM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Register-operand form of the u8 coarse pass (round 3, PM_OPT_KNN_RING = 4).  The stamps and ablations of the two
+// LDS forms above say the same thing three times: at the i8 rate the hand-off of a tile between the waves that fill it
+// and the waves that read it costs as much as the tile's MFMAs, whatever the primitive.  With 128-byte rows the
+// hand-off is not needed at all: a wave can hold 128 queries as B operands for the whole kernel (4 blocks x 4 k-chunks
+// x 4 VGPRs = 64 registers) and read its A operands — 32 train rows = 4 KiB per block — STRAIGHT FROM GLOBAL MEMORY into
+// registers (4 x global_load_dwordx4 per lane, one block ahead), plus the block's 16 C-in seeds (4 more loads, two
+// distinct addresses per instruction).  The eight waves of a workgroup own the same 128 queries and take the 32-row
+// blocks of the split in turn (wave w: blocks w, w + 8, ...), so every train row still enters the CU once per workgroup,
+// nothing is staged in LDS, and there is no barrier before the final merge of the eight waves' candidate lists.
+// Same candidate format and numbering as knn_mfma_rows288<RouteU8T<GPB>> (group id = block-in-split * GPB + g).
+// ---------------------------------------------------------------------------------------------
+constexpr int RA_NQB = 4;                // query blocks per wave: 128 queries per workgroup
+constexpr int RA_WAVES = 8;
+constexpr int RA_QB = 32 * RA_NQB;
+
+// PRIV: the A operands go through a PRIVATE LDS buffer of the wave instead (LDS-DMA, five coalesced 1-KiB pieces per block:
+// a dwordx4 load whose lanes sit 128 bytes apart touches 32 cache lines for 1 KiB and the texture path takes a line per
+// clock — measured: the straight-to-register form is 2x SLOWER than the tile kernels at 32k x 32k).  Still no hand-off:
+// a wave waits for its own pieces only (counted vmcnt), reads them back with ds_read_b128 and never meets another wave
+// before the final merge.
+constexpr int RA_PIECES = 5;                                   // 32 rows x 144 B = 4.5 KiB
+constexpr int RA_PRIV_SLOTS = RA_PIECES * 64;                  // 16-byte slots per private buffer
+
+// WSPLIT: every WAVE owns a train split of its own (split = 8 * blockIdx.y + wave: up to 2048 consecutive rows) instead of
+// every eighth block of the workgroup's split: the waves of a workgroup then share nothing but their 128 queries, there
+// is no merge and no barrier at all, and a wave's entry cost (16 query-fragment loads) is spread over up to 64 blocks
+// instead of 8.  Needs long sweeps: the host takes it when a split is >= 1024 rows with every CU busy.
+template <int GPB_, bool PRIV, bool WSPLIT, typename ABL>
+__global__ __launch_bounds__(RA_WAVES * 64, 1) void knn_u8_rega(const uint4* __restrict__ Q8, const uint4* __restrict__ T8,
+                                                               const uint4* __restrict__ seeds_g, int nq, int nt, int tiles_per_split,
+                                                               i32x4* __restrict__ cand_val, int slots, int mode)
+{
+    typedef RouteU8T<GPB_> R;
+    typedef typename R::frag frag;
+    typedef typename R::acc acc;
+    typedef typename R::list list;
+    __shared__ list xs[RA_WAVES][RA_NQB][64];
+    extern __shared__ __attribute__((aligned(16))) uint4 psm[];       // PRIV: [RA_WAVES][3][RA_PRIV_SLOTS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const WgTile wg = wg_tile((mode & 2) != 0);
+    // WSPLIT: waves w and w + 4 sweep the SAME split for two different sets of 128 queries (a workgroup = 256 queries x 4
+    // splits): they run in step, so the second request for a piece is served by the CU's L1 and the L2 -> CU traffic per
+    // descriptor pair is that of the 256-query tile kernels
+    const int qbase = WSPLIT ? wg.qb * (2 * RA_QB) + (wave >> 2) * RA_QB : wg.qb * RA_QB;
+
+    const int ntiles = (nt + H_TT - 1) / H_TT;
+    const int my_split = WSPLIT ? wg.split * (RA_WAVES / 2) + (wave & 3) : wg.split;
+    const int tile0 = my_split * tiles_per_split;
+    int tile1 = tile0 + tiles_per_split;
+    if (tile1 > ntiles) tile1 = ntiles;
+    const int nblocks = tile1 > tile0 ? (tile1 - tile0) * 4 : 0;     // 32-row blocks of this split
+    const int block0 = tile0 * 4;
+    constexpr int STEP = WSPLIT ? 1 : RA_WAVES;                      // block stride of a wave
+    if (WSPLIT && nblocks == 0) return;                              // (no barrier in this form)
+
+    struct Ops { frag a[U8_NCH]; Seed64 s; };
+    // PRIV: source offset (bytes inside the block) of this lane's slot of each DMA piece; a lane that lands in a row's pad
+    // slot, or behind the 32nd row, re-reads a valid unit (never used)
+    // WSPLIT: the train copy has 144-byte rows (knn_shared.hpp, "wide" rows): the LDS image of a block IS its memory
+    // image, pieces are lane-linear and the block's seeds arrive in the pad slots of its first eight rows
+    constexpr int T_ROW_BYTES = (WSPLIT ? U8_WIDE_ROW16 : U8_ROW16) * 16;
+    int src[RA_PIECES];
+#pragma unroll
+    for (int p = 0; p < RA_PIECES; ++p) {
+        const int sl = 64 * p + lane, row = sl / U8_LDS_ROW16, u = sl % U8_LDS_ROW16;
+        if (WSPLIT) src[p] = (sl < 32 * U8_LDS_ROW16 ? sl : 32 * U8_LDS_ROW16 - 1) * 16;
+        else src[p] = (row < 32 ? row : 31) * (U8_ROW16 * 16) + (u < U8_ROW16 ? u : U8_ROW16 - 1) * 16;
+    }
+    const __amdgpu_buffer_rsrc_t t_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4*>(T8), 0, ntiles * (H_TT * T_ROW_BYTES), 0x00020000);
+    uint4* const mine = psm + wave * (3 * RA_PRIV_SLOTS);
+    auto load_ops = [&](int blk, Ops& o, int buf) {         // blk: block inside the split (clamped by the caller)
+        if constexpr (PRIV) {
+            typedef __attribute__((address_space(3))) void* lptr_t;
+            const int soff = (block0 + blk) * (32 * T_ROW_BYTES);
+#pragma unroll
+            for (int p = 0; p < RA_PIECES; ++p)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(t_rsrc, (lptr_t)(mine + buf * RA_PRIV_SLOTS + 64 * p), 16, src[p], soff, 0, 0);
+        } else {
+            const uint4* tp = T8 + (static_cast<size_t>(block0 + blk) * 32 + r) * U8_ROW16 + h;
+#pragma unroll
+            for (int c = 0; c < U8_NCH; ++c) o.a[c] = *reinterpret_cast<const frag*>(tp + 2 * c);
+        }
+        const uint4* sp = seeds_g + static_cast<size_t>(block0 + blk) * 8 + 4 * h;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (WSPLIT) { }                                            // (seeds: with the pieces, read from LDS)
+            else if constexpr (PRIV && ABL::no_ldsread) o.s.v[i] = uint4{0u, 0u, 0u, 0u};   // timing-only build: no seed loads
+            else if constexpr (PRIV) o.s.v[i] = untracked_load16<uint4>(sp + i);  // (waited for by count, with the pieces)
+            else o.s.v[i] = sp[i];
+        }
+    };
+    constexpr int OPS_PER_BLOCK = RA_PIECES + ((WSPLIT || ABL::no_ldsread) ? 0 : 4);
+    ABL::stamp(0);
+    Ops o0, o1;
+    int b = WSPLIT ? 0 : wave;
+    if (!PRIV && b < nblocks) load_ops(b, o0, 0);           // first block's operands, then the query fragments
+    frag qf[RA_NQB][U8_NCH];
+#pragma unroll
+    for (int qb = 0; qb < RA_NQB; ++qb)
+#pragma unroll
+        for (int c = 0; c < U8_NCH; ++c)
+            qf[qb][c] = *reinterpret_cast<const frag*>(Q8 + static_cast<size_t>(qbase + 32 * qb + r) * U8_ROW16 + 2 * c + h);
+    if constexpr (PRIV) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the counted waits below start from a clean slate)
+#pragma unroll
+    for (int qb = 0; qb < RA_NQB; ++qb)
+#pragma unroll
+        for (int c = 0; c < U8_NCH; ++c) {                  // opaque: never re-read from memory inside the loop
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 t = __builtin_bit_cast(u32x4, qf[qb][c]);
+            asm volatile("" : "+v"(t));
+            qf[qb][c] = __builtin_bit_cast(frag, t);
+        }
+    list cl[RA_NQB];
+#pragma unroll
+    for (int qb = 0; qb < RA_NQB; ++qb) cl[qb] = R::empty();
+    ABL::stamp(1);
+    if (PRIV && !WSPLIT && b < nblocks) load_ops(b, o0, 0);
+
+    auto block = [&](Ops& o, int blk, int buf) {
+        const int sk = blk / STEP - 4;                      // diagnostic builds: the wave's 5th .. 7th block, four stamps each
+        if (sk >= 0 && sk < 3) ABL::stamp(2 + 4 * sk);
+        if constexpr (PRIV) {
+            // this block's pieces and seeds have landed once at most the next TWO blocks' requests are outstanding
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPS_PER_BLOCK) : "memory");
+            if constexpr (WSPLIT) {
+                const uint4* sq = mine + buf * RA_PRIV_SLOTS + 4 * h * U8_LDS_ROW16 + U8_ROW16;     // pad slots of rows 4h .. 4h+3
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o.s.v[i] = sq[i * U8_LDS_ROW16];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pin_after_wait(o.s.v[i]);
+            }
+            const uint4* tb = mine + buf * RA_PRIV_SLOTS + r * U8_LDS_ROW16 + h;
+#pragma unroll
+            for (int c = 0; c < U8_NCH; ++c) o.a[c] = *reinterpret_cast<const frag*>(tb + 2 * c);
+        }
+        if (sk >= 0 && sk < 3) ABL::stamp(3 + 4 * sk);
+        const acc seed = __builtin_bit_cast(acc, o.s);
+        acc a[RA_NQB];
+        // The two waves of a SIMD start in step and the issue arbiter keeps them there: both in their 16-MFMA chain (sharing
+        // the matrix pipe), then both in their selection (sharing the VALU) — nothing overlaps.  Raised priority over the
+        // chain lets ONE wave run its chain at full rate while the other selects; they then alternate.
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int c = 0; c < U8_NCH; ++c)
+#pragma unroll
+            for (int qb = 0; qb < RA_NQB; ++qb) a[qb] = R::mfma(o.a[c], qf[qb][c], c == 0 ? seed : a[qb]);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(0);
+        if (sk >= 0 && sk < 3) ABL::stamp(4 + 4 * sk);
+        if constexpr (ABL::no_epi) {
+#pragma unroll
+            for (int qb = 0; qb < RA_NQB; ++qb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(a[qb][e]));
+        } else {
+            const unsigned gb = static_cast<unsigned>(blk) * R::GPB;
+#pragma unroll
+            for (int qb = 0; qb < RA_NQB; ++qb)
+#pragma unroll
+                for (int g = 0; g < R::GPB; ++g) R::select(a[qb], 0u, (gb + static_cast<unsigned>(g)) << 1, cl[qb], g);
+        }
+        if (sk >= 0 && sk < 3) {
+            asm volatile("" : "+v"(cl[0][0]), "+v"(cl[RA_NQB - 1][3]));
+            ABL::stamp(5 + 4 * sk);
+        }
+    };
+    if constexpr (WSPLIT) {
+        // Split per wave: pieces two blocks ahead in three private buffers (runtime buffer index), and TWO accumulator sets:
+        // the selection of block b - 1 is issued between the MFMAs of block b (chunks 1 .. 3), as in h_block — stamps of the
+        // version that selected a block right after its own MFMAs showed the two waves of a SIMD in step, both in their
+        // MFMA chain and then both in their selection, the matrix pipe idle for ~40 % of a block.
+        acc accA[RA_NQB], accB[RA_NQB];
+        auto issue = [&](int blk, int buf) {
+            typedef __attribute__((address_space(3))) void* lptr_t;
+            const int soff = (block0 + blk) * (32 * T_ROW_BYTES);
+#pragma unroll
+            for (int p = 0; p < RA_PIECES; ++p)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(t_rsrc, (lptr_t)(mine + buf * RA_PRIV_SLOTS + 64 * p), 16, src[p], soff, 0, 0);
+        };
+        auto select_all = [&](const acc (&p)[RA_NQB], int blk) {
+            const unsigned gb = static_cast<unsigned>(blk) * R::GPB;
+#pragma unroll
+            for (int qb = 0; qb < RA_NQB; ++qb)
+#pragma unroll
+                for (int g = 0; g < R::GPB; ++g) R::select(p[qb], 0u, (gb + static_cast<unsigned>(g)) << 1, cl[qb], g);
+        };
+        auto wblock = [&](int buf, int blk, acc (&cur)[RA_NQB], const acc (&prev)[RA_NQB], auto has_prev) {
+            const int sk = blk - 4;
+            if (sk >= 0 && sk < 3) ABL::stamp(2 + 4 * sk);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * RA_PIECES) : "memory");      // this block's pieces have landed
+            const uint4* base = mine + buf * RA_PRIV_SLOTS;
+            Seed64 sd;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sd.v[i] = base[(4 * h + i) * U8_LDS_ROW16 + U8_ROW16];   // pad slots of rows 4h .. 4h+3
+            frag a[U8_NCH];
+#pragma unroll
+            for (int c = 0; c < U8_NCH; ++c) a[c] = *reinterpret_cast<const frag*>(base + r * U8_LDS_ROW16 + h + 2 * c);
+            if (sk >= 0 && sk < 3) ABL::stamp(3 + 4 * sk);
+            const acc seed = __builtin_bit_cast(acc, sd);
+            const unsigned gb = static_cast<unsigned>(blk - 1) * R::GPB;
+            constexpr int NGB = R::GPB * RA_NQB;
+#pragma unroll
+            for (int c = 0; c < U8_NCH; ++c) {
+#pragma unroll
+                for (int qb = 0; qb < RA_NQB; ++qb) cur[qb] = R::mfma(a[c], qf[qb][c], c == 0 ? seed : cur[qb]);
+                if constexpr (decltype(has_prev)::value) {
+                    if (c >= 1) {
+                        if constexpr (ABL::no_epi) {
+                            if (c == 1) {
+#pragma unroll
+                                for (int qb = 0; qb < RA_NQB; ++qb)
+#pragma unroll
+                                    for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(prev[qb][e]));
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = (c - 1) * NGB / (U8_NCH - 1); e < c * NGB / (U8_NCH - 1); ++e)
+                                R::select(prev[e % RA_NQB], 0u, (gb + static_cast<unsigned>(e / RA_NQB)) << 1, cl[e % RA_NQB], e / RA_NQB);
+                            // pin the selection to this chunk (hipcc otherwise sinks all of it below the last MFMA)
+                            asm volatile("" : "+v"(cl[0][0]), "+v"(cl[1][0]), "+v"(cl[2][0]), "+v"(cl[3][0]));
+                        }
+                    }
+                }
+            }
+            if (sk >= 0 && sk < 3) { ABL::stamp(4 + 4 * sk); ABL::stamp(5 + 4 * sk); }
+        };
+        const int last = nblocks - 1;
+        int bc = 0, bn = 2;                                  // buffer of the current block, buffer two blocks ahead
+        issue(0, 0);
+        issue(1 < last ? 1 : last, 1);
+        b = 0;
+        issue(2 < last ? 2 : last, 2);
+        wblock(0, 0, accA, accB, std::false_type{});          // block b accumulates in accA (b even) / accB (b odd)
+        b = 1; bc = 1; bn = 0;
+        while (true) {
+            if (b >= nblocks) break;
+            issue(b + 2 < last ? b + 2 : last, bn);
+            wblock(bc, b, accB, accA, std::true_type{});
+            ++b; bc = bc == 2 ? 0 : bc + 1; bn = bn == 2 ? 0 : bn + 1;
+            if (b >= nblocks) break;
+            issue(b + 2 < last ? b + 2 : last, bn);
+            wblock(bc, b, accA, accB, std::true_type{});
+            ++b; bc = bc == 2 ? 0 : bc + 1; bn = bn == 2 ? 0 : bn + 1;
+        }
+        // the last block's accumulators: in accA if an odd number of blocks ran the loop... (b - 1 is even <=> accA)
+        if constexpr (!ABL::no_epi) {
+            if (((nblocks - 1) & 1) == 0) select_all(accA, nblocks - 1);
+            else select_all(accB, nblocks - 1);
+        }
+    } else if constexpr (PRIV) {
+        // THREE operand sets in turn, two blocks ahead: stamps of the first version (one block ahead) showed a wave waiting
+        // ~1200-1500 cycles per block for pieces it had requested one block (~1100 cycles) earlier — under load an
+        // L2-served LDS-DMA piece takes ~2000+ cycles.  Requests are clamped to the wave's last block, so every block costs
+        // exactly RA_PIECES + 4 vector-memory operations and the waits can be counted.
+        const int last = nblocks > 0 ? b + (nblocks - 1 - b) / STEP * STEP : 0;
+        Ops o2;
+        if (b < nblocks) {
+            load_ops(b + STEP < last ? b + STEP : last, o1, 1);
+            while (true) {
+                load_ops(b + 2 * STEP < last ? b + 2 * STEP : last, o2, 2);
+                block(o0, b, 0);
+                b += STEP;
+                if (b >= nblocks) break;
+                load_ops(b + 2 * STEP < last ? b + 2 * STEP : last, o0, 0);
+                block(o1, b, 1);
+                b += STEP;
+                if (b >= nblocks) break;
+                load_ops(b + 2 * STEP < last ? b + 2 * STEP : last, o1, 1);
+                block(o2, b, 2);
+                b += STEP;
+                if (b >= nblocks) break;
+            }
+        }
+    } else {
+    // two operand sets in turn: block b + 8 is in flight while block b is multiplied
+    while (b < nblocks) {
+        const int b1 = b + STEP;
+        load_ops(b1 < nblocks ? b1 : b, o1, 1);             // (clamped: a valid address either way)
+        block(o0, b, 0);
+        if (b1 >= nblocks) break;
+        const int b2 = b1 + STEP;
+        load_ops(b2 < nblocks ? b2 : b1, o0, 0);
+        block(o1, b1, 1);
+        b = b2;
+    }
+    }
+    if constexpr (PRIV) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA in flight when the wave ends
+    ABL::stamp(16);
+
+    if constexpr (WSPLIT) {
+#pragma unroll
+        for (int qb = 0; qb < RA_NQB; ++qb) {
+            R::merge(cl[qb], h);
+            const int q = qbase + 32 * qb + r;
+            if (q < nq && h == 0) cand_val[(static_cast<size_t>(q) * slots + my_split * KNN_C) / KNN_C] = cl[qb];
+        }
+        ABL::stamp(17);
+        return;
+    }
+    // the eight waves' lists of a query meet in LDS; wave w < 4 finishes query block w
+#pragma unroll
+    for (int qb = 0; qb < RA_NQB; ++qb) {
+        R::merge(cl[qb], h);
+        xs[wave][qb][lane] = cl[qb];
+    }
+    __syncthreads();
+    if (wave >= RA_NQB) return;
+    list out = xs[0][wave][lane];
+#pragma unroll
+    for (int w = 1; w < RA_WAVES; ++w) {
+        const list o = xs[w][wave][lane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) R::put(out, o[i]);
+    }
+    const int q = qbase + 32 * wave + r;
+    if (q < nq && h == 0) cand_val[(static_cast<size_t>(q) * slots + wg.split * KNN_C) / KNN_C] = out;
+}
+
+template <int GPB_, typename ABL>
+int launch_rega(pm_ctx* ctx, const char* name, const void* Q8, const void* T8, const void* seeds, int nq, int nq_pad, int nt,
+                int splits, int tiles_per_split, void* cval, int slots, int form)
+{
+    PM_REQUIRE(nq_pad % RA_QB == 0, PM_E_INVALID, "query padding does not match the workgroup size");
+    pm::ScopedKernelTime t(ctx, name);
+    const int mode = xcd_tiled(ctx) ? 2 : 0;
+    const uint4* q4 = static_cast<const uint4*>(Q8);
+    const uint4* t4 = static_cast<const uint4*>(T8);
+    const uint4* s4 = static_cast<const uint4*>(seeds);
+    i32x4* out = static_cast<i32x4*>(cval);
+    if (form >= 5) {       // 5: private LDS buffers, blocks dealt round-robin; 6: private LDS buffers, a split per wave
+        PM_REQUIRE(rows288_dma_ok<RouteU8T<GPB_>>(nt) && (static_cast<long long>(nt) + 2 * H_TT) * (U8_WIDE_ROW16 * 16) < 0x7FFFFFFFLL,
+                   PM_E_UNSUPPORTED, "train set too large for the LDS-DMA coarse routes");
+        const size_t lds = sizeof(uint4) * RA_WAVES * 3 * RA_PRIV_SLOTS;
+        static bool attr_done_dev[PM_MAX_DEVICES] = {};
+        if (!attr_done_dev[ctx->device]) {
+            PM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_u8_rega<GPB_, true, false, ABL>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+            PM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_u8_rega<GPB_, true, true, ABL>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+            attr_done_dev[ctx->device] = true;
+        }
+        if (form == 6)
+            hipLaunchKernelGGL((knn_u8_rega<GPB_, true, true, ABL>), dim3(nq_pad / (2 * RA_QB), (splits + RA_WAVES / 2 - 1) / (RA_WAVES / 2)),
+                               dim3(RA_WAVES * 64), lds, ctx->stream, q4, t4, s4, nq, nt, tiles_per_split, out, slots, mode);
+        else
+            hipLaunchKernelGGL((knn_u8_rega<GPB_, true, false, ABL>), dim3(nq_pad / RA_QB, splits), dim3(RA_WAVES * 64), lds,
+                               ctx->stream, q4, t4, s4, nq, nt, tiles_per_split, out, slots, mode);
+    } else {
+        hipLaunchKernelGGL((knn_u8_rega<GPB_, false, false, ABL>), dim3(nq_pad / RA_QB, splits), dim3(RA_WAVES * 64), 0, ctx->stream,
+                           q4, t4, s4, nq, nt, tiles_per_split, out, slots, mode);
+    }
+    PM_HIP_CHECK(hipGetLastError());
+    return PM_OK;
+}
+
 // u8 route: group size (rows per candidate group) x staging form
 template <typename ABL>
 int coarse_u8_dispatch(pm_ctx* ctx, const void* Q8, const void* T8, const int* seeds, int nq, int nq_pad, int nt, int splits,
-                       int tiles_per_split, int* cval, int slots, int group_rows, bool ring)
+                       int tiles_per_split, int* cval, int slots, int group_rows, int form)
 {
-    // the ring form (measured, not the default: see knn_mfma_ring) exists for the default group size only
-    if (ring && group_rows == 8)
+    // form: 0 / 1 two LDS tile buffers, 2 / 3 ring of eight, 4 / 5 / 6 register-operand forms (the caller sized the grid
+    // and the splits for 128 queries per workgroup); 2 .. 6 exist for the default group size only
+    if (form >= 4 && group_rows == 8)
+        return launch_rega<2, ABL>(ctx, "knn_l2_mfma_u8", Q8, T8, seeds, nq, nq_pad, nt, splits, tiles_per_split, cval, slots, form);
+    if (form >= 2 && group_rows == 8)
         return launch_ring<RouteU8T<2>, 8, ABL>(ctx, "knn_l2_mfma_u8", Q8, T8, seeds, nq, nq_pad, nt, splits, tiles_per_split, 0u, cval, slots);
 #define PM_U8(GPB_)                                                                                                        \
     launch_rows288<RouteU8T<GPB_>, ABL>(ctx, "knn_l2_mfma_u8", Q8, T8, seeds, nq, nq_pad, nt, splits, tiles_per_split, 0u, cval,   \

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void knn_l2_prep8(const float* __restrict__ Q,
                                                     float* __restrict__ qnorm, float* __restrict__ tnorm,
                                                     uint2* __restrict__ Q8, uint2* __restrict__ T8,
                                                     int* __restrict__ seeds, unsigned long long* __restrict__ stats,
-                                                    unsigned epoch)
+                                                    unsigned epoch, int t_wide)
 {
     __shared__ unsigned wbad[4];
     const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
@@ -373,11 +373,12 @@ __global__ __launch_bounds__(256) void knn_l2_prep8(const float* __restrict__ Q,
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
         if (!okrow) bad |= 2u;
-        x8[static_cast<size_t>(row) * (U8_DP / 8) + sub] = uint2{w[0], w[1]};
+        x8[static_cast<size_t>(row) * ((is_t && t_wide) ? U8_WIDE_ROW16 * 2 : U8_DP / 8) + sub] = uint2{w[0], w[1]};
         if (sub == 0) {
             const int si = static_cast<int>(s);
             if (is_t) {
                 seeds[seed_pos(row)] = live ? -(si >> 1) : U8_PAD_SEED;
+                if (t_wide) reinterpret_cast<int*>(T8)[u8_wide_seed_index(row)] = live ? -(si >> 1) : U8_PAD_SEED;
                 if (live) tnorm[row] = s;                     // ||t - 128||^2 (an exact integer: the integer refinement's row term)
             } else if (live) {
                 qnorm[row] = s;
@@ -400,7 +401,8 @@ __global__ __launch_bounds__(256) void knn_l2_prep8(const float* __restrict__ Q,
 __global__ __launch_bounds__(256) void knn_l2_prep8_u8(const uint8_t* __restrict__ Q, int nq, int nq_pad,
                                                        const uint8_t* __restrict__ T, int nt, int nt_pad, int dim,
                                                        float* __restrict__ qnorm, float* __restrict__ tnorm,
-                                                       uint2* __restrict__ Q8, uint2* __restrict__ T8, int* __restrict__ seeds)
+                                                       uint2* __restrict__ Q8, uint2* __restrict__ T8, int* __restrict__ seeds,
+                                                       int t_wide)
 {
     const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const int qblocks = nq_pad / 64;
@@ -434,10 +436,11 @@ __global__ __launch_bounds__(256) void knn_l2_prep8_u8(const uint8_t* __restrict
         }
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) si += __shfl_xor(si, o, 16);
-        x8[static_cast<size_t>(row) * (U8_DP / 8) + sub] = uint2{w[0], w[1]};
+        x8[static_cast<size_t>(row) * ((is_t && t_wide) ? U8_WIDE_ROW16 * 2 : U8_DP / 8) + sub] = uint2{w[0], w[1]};
         if (sub == 0) {
             if (is_t) {
                 seeds[seed_pos(row)] = live ? -(si >> 1) : U8_PAD_SEED;
+                if (t_wide) reinterpret_cast<int*>(T8)[u8_wide_seed_index(row)] = live ? -(si >> 1) : U8_PAD_SEED;
                 if (live) tnorm[row] = static_cast<float>(si);
             } else if (live) {
                 qnorm[row] = static_cast<float>(si);
@@ -1006,9 +1009,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void knn_
 // 64 rows cost what one costs).  A wrong hint (bit 1 of stats[1]) sends every query to the canonical f32 scan.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int u8_row_d2(const uint4 (&qv)[U8_ROW16], const uint4* __restrict__ T8, int row, int qn,
-                                         const float* __restrict__ tnorm)
+                                         const float* __restrict__ tnorm, int t_row16)
 {
-    const uint4* tp = T8 + static_cast<size_t>(row) * U8_ROW16;
+    const uint4* tp = T8 + static_cast<size_t>(row) * t_row16;
     uint4 tv[U8_ROW16];
 #pragma unroll
     for (int i = 0; i < U8_ROW16; ++i) tv[i] = tp[i];
@@ -1055,7 +1058,7 @@ __global__ __launch_bounds__(256) void knn_l2_refine8(
     const float* __restrict__ Q, const float* __restrict__ T, const uint4* __restrict__ Q8, const uint4* __restrict__ T8,
     const float* __restrict__ qnorm, const float* __restrict__ tnorm, const int* __restrict__ cand,
     const unsigned long long* __restrict__ stats, unsigned epoch, unsigned* __restrict__ diag, int nq, int nt, int dim, int k,
-    int slots, int tiles_per_split, pm_match* __restrict__ out, KnnFuse fz)
+    int slots, int tiles_per_split, pm_match* __restrict__ out, KnnFuse fz, int t_row16)
 {
     constexpr int GPB = 16 / GROUP;                          // groups per 32-row block and lane half
     constexpr int IMAX = 0x7FFFFFFF;
@@ -1126,7 +1129,7 @@ __global__ __launch_bounds__(256) void knn_l2_refine8(
     BestN<KM> b;
     b.init();
     auto take = [&](int row) {
-        const int d2 = u8_row_d2(qv, T8, row, qn, tnorm);
+        const int d2 = u8_row_d2(qv, T8, row, qn, tnorm, t_row16);
         const float d = __builtin_sqrtf(static_cast<float>(d2));
         b.insert(knn_key(d, row), d);
     };
@@ -1527,10 +1530,27 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
     }
     // ---- f16 route geometry: 128-row tiles, 256 queries per workgroup (4 waves x 64)
     // (u8 ring kernel in its 16-wave form, PM_OPT_KNN_F16_WAVES = 3: 512 queries per workgroup)
-    const int qb_wg = ((flags & PM_KNN_HINT_U8) && !(flags & PM_KNN_FORCE_F32) && ctx->opts[PM_OPT_KNN_RING] >= 2 &&
-                       ctx->opts[PM_OPT_KNN_U8_GROUP] != 1 && ctx->opts[PM_OPT_KNN_U8_GROUP] != 3 &&
-                       ctx->opts[PM_OPT_KNN_F16_WAVES] == 3) ? 512 : H_QB;
-    const int nq_pad = (nq + qb_wg - 1) / qb_wg * qb_wg, nt_pad = (nt + H_TT - 1) / H_TT * H_TT;
+    // u8 coarse kernel form (PM_OPT_KNN_RING): 1 two LDS tile buffers, 2 / 3 ring, 4 / 5 register-operand forms (128 queries
+    // per workgroup), 6 register-operand form with a split per WAVE — long sweeps only: taken when every CU stays busy with
+    // splits of at least 8 tiles (1024 rows), else the two-buffer tile kernel runs
+    const bool u8_default_group = ctx->opts[PM_OPT_KNN_U8_GROUP] != 1 && ctx->opts[PM_OPT_KNN_U8_GROUP] != 3;
+    const bool u8_asked = ((flags & PM_KNN_HINT_U8) || u8in) && !(flags & PM_KNN_FORCE_F32);
+    int u8_form = (u8_asked && u8_default_group) ? ctx->opts[PM_OPT_KNN_RING] : 1;
+    int ws_splits = 0;
+    if (u8_form == 6) {
+        const int ntl = (nt + H_TT - 1) / H_TT, nqb128 = (nq + H_QB - 1) / H_QB * 2;
+        int sp = (8 * ctx->n_cu + nqb128 - 1) / nqb128;                // 8 waves per workgroup, one split each
+        if (sp < (ntl + 15) / 16) sp = (ntl + 15) / 16;
+        if (sp > 64) sp = 64;
+        if (sp > ntl) sp = ntl;
+        if (sp < 1) sp = 1;
+        const int tps = (ntl + sp - 1) / sp;
+        const bool fits = (static_cast<long long>(nt) + 3 * H_TT) * (U8_WIDE_ROW16 * 16) < 0x7FFFFFFFLL;   // 32-bit DMA offsets
+        if (tps >= 8 && tps <= 16 && fits) ws_splits = sp; else u8_form = 1;
+    }
+    const int qb_wg = u8_form >= 4 ? 128 : (u8_form >= 2 && ctx->opts[PM_OPT_KNN_F16_WAVES] == 3) ? 512 : H_QB;
+    const int q_unit = qb_wg > H_QB ? qb_wg : H_QB;           // (a multiple of 256 also when workgroups take 128 queries)
+    const int nq_pad = (nq + q_unit - 1) / q_unit * q_unit, nt_pad = (nt + H_TT - 1) / H_TT * H_TT;
     {
         const int nqb = nq_pad / qb_wg;
         const int ntiles = nt_pad / H_TT;
@@ -1538,7 +1558,7 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
         // two co-resident ones did with register staging (C3: 18.9 vs 19.0-21.7 us, 4096 x 4096: 10.0 vs 11.6 us), and half
         // the splits are half the candidate lists the refinement has to read.  PM_OPT_KNN_WG_PER_CU = 2: two per CU.
         const int wg_per_cu = ctx->opts[PM_OPT_KNN_WG_PER_CU] == 2 ? 2 : 1;
-        int splits = (wg_per_cu * ctx->n_cu + nqb - 1) / nqb;
+        int splits = ws_splits ? ws_splits : (wg_per_cu * ctx->n_cu + nqb - 1) / nqb;
         if (splits < (ntiles + 15) / 16) splits = (ntiles + 15) / 16;          // <= 2048 rows per split (see above)
         if (splits > ntiles) splits = ntiles;
         if (splits > 64) splits = 64;
@@ -1594,7 +1614,8 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
     const size_t c16 = want16 ? sizeof(float) * static_cast<size_t>(nq) * g16.slots : 0;
     const size_t rowb = u8r ? U8_DP : sizeof(_Float16) * (f16s ? H_DP : dp16 + 16);   // bytes per row of the coarse copies
     const size_t qh = want16 ? rowb * static_cast<size_t>(nq_pad) : 0;
-    const size_t th = want16 ? rowb * static_cast<size_t>(nt_pad) : 0;
+    const int t_wide = (u8r && u8_form == 6) ? 1 : 0;            // 144-byte train rows with the seeds in the pad slots (knn_u8_rega)
+    const size_t th = want16 ? (t_wide ? static_cast<size_t>(U8_WIDE_ROW16) * 16 : rowb) * static_cast<size_t>(nt_pad) : 0;
     const size_t sdb = (u8r || f16s) ? 4 * static_cast<size_t>(nt_pad + H_TT) : 0;       // seeds (+ one tile of slack)
     const size_t pkb = fuse ? sizeof(unsigned long long) * static_cast<size_t>(nq) : 0;
     const size_t need = pm::align_up(sizeof(float) * nq, 256) + pm::align_up(sizeof(float) * nt, 256) +
@@ -1639,15 +1660,15 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
         if (u8in)
             hipLaunchKernelGGL(knn_l2_prep8_u8, dim3(nq_pad / 64 + nt_pad / 64), dim3(256), 0, ctx->stream, uq, nq, nq_pad, ut, nt,
                                nt_pad, dim, qnorm, tnorm, reinterpret_cast<uint2*>(Qh), reinterpret_cast<uint2*>(Th),
-                               static_cast<int*>(seeds));
+                               static_cast<int*>(seeds), t_wide);
         else if (u8r && ctx->opts[PM_OPT_KNN_PREP_ROWS] != 1)      // 16 rows per workgroup: matcher call 23.5 -> 22.2 us at C3, 15.1 -> 14.2 at C2
             hipLaunchKernelGGL(knn_l2_prep8<1>, dim3(nq_pad / 16 + nt_pad / 16), dim3(256), 0, ctx->stream, dq, nq, nq_pad, dt,
                                nt, nt_pad, dim, qnorm, tnorm, reinterpret_cast<uint2*>(Qh), reinterpret_cast<uint2*>(Th),
-                               static_cast<int*>(seeds), stats, epoch);
+                               static_cast<int*>(seeds), stats, epoch, t_wide);
         else if (u8r)
             hipLaunchKernelGGL(knn_l2_prep8<4>, dim3(nq_pad / 64 + nt_pad / 64), dim3(256), 0, ctx->stream, dq, nq, nq_pad, dt,
                                nt, nt_pad, dim, qnorm, tnorm, reinterpret_cast<uint2*>(Qh), reinterpret_cast<uint2*>(Th),
-                               static_cast<int*>(seeds), stats, epoch);
+                               static_cast<int*>(seeds), stats, epoch, t_wide);
         else if (f16s)
             hipLaunchKernelGGL((knn_l2_prep16<true, 128, true>), dim3(nq_pad / 64 + nt_pad / 64), dim3(256), 0, ctx->stream, dq, nq,
                                nq_pad, dt, nt, nt_pad, dim, qnorm, tnorm, Qh, Th, static_cast<float*>(seeds), stats, epoch);
@@ -1678,7 +1699,7 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
     }
     if (u8r) {
         rc = launch_coarse_u8(ctx, Qh, Th, static_cast<const int*>(seeds), nq, nq_pad, nt, splits16, g16.tiles_per_split,
-                              reinterpret_cast<int*>(cval16), g16.slots, u8_group, ctx->opts[PM_OPT_KNN_RING] >= 2);
+                              reinterpret_cast<int*>(cval16), g16.slots, u8_group, u8_form);
         if (rc != PM_OK) return rc;
     } else if (f16s) {
         rc = launch_coarse_f16s(ctx, Qh, Th, static_cast<const float*>(seeds), nq, nq_pad, nt, splits16, g16.tiles_per_split,
@@ -1699,7 +1720,8 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
 #define PM_R8K(NS_, GROUP_, KM_, FUSE_)                                                                                    \
     hipLaunchKernelGGL((knn_l2_refine8<NS_, GROUP_, KM_, FUSE_>), dim3((nq + 15) / 16), dim3(256), 0, ctx->stream, dq, dt,  \
                        reinterpret_cast<const uint4*>(Qh), reinterpret_cast<const uint4*>(Th), qnorm, tnorm,               \
-                       reinterpret_cast<const int*>(cval16), stats, epoch, diag, nq, nt, dim, k, g16.slots, g16.tiles_per_split, dout, fz)
+                       reinterpret_cast<const int*>(cval16), stats, epoch, diag, nq, nt, dim, k, g16.slots, g16.tiles_per_split, dout, fz, \
+                       t_wide ? U8_WIDE_ROW16 : U8_ROW16)
 #define PM_R8(NS_, GROUP_) do { if (fuse) PM_R8K(NS_, GROUP_, 2, true); else if (k <= 2) PM_R8K(NS_, GROUP_, 2, false); else PM_R8K(NS_, GROUP_, 4, false); } while (0)
 #define PM_R8G(NS_) do { if (u8_group == 4) PM_R8(NS_, 4); else if (u8_group == 8) PM_R8(NS_, 8); else PM_R8(NS_, 16); } while (0)
         if (g16.slots <= 16) PM_R8G(1);                      // slots of a query per lane of its 16-lane row

@@ -68,13 +68,25 @@ __host__ __device__ inline int seed_pos(int row)
     return (row & ~31) + 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3);
 }
 
+// "wide" train rows of the register-operand coarse form with a split per wave (knn_u8_rega<.., WSPLIT>): 144 bytes = the
+// LDS image of a row, so a 32-row block is 4.5 KiB of contiguous memory that LDS-DMA copies as it is; the 16-byte pad slot
+// of row j < 8 of a block holds the block's seeds at seed-order positions 4j .. 4j+3 (a lane half's 16 C-in values are
+// the pad slots of rows 4h .. 4h+3: four ds_read_b128).  Pad slots of rows 8 .. 31 are unused.
+constexpr int U8_WIDE_ROW16 = 9;
+__host__ __device__ inline size_t u8_wide_seed_index(int row)           // index, in ints, into the wide train copy
+{
+    const int p = seed_pos(row) - (row & ~31);
+    return (static_cast<size_t>(row & ~31) + (p >> 2)) * (U8_WIDE_ROW16 * 4) + U8_ROW16 * 4 + (p & 3);
+}
+
 // Enqueue the seeded coarse passes.  Q8/T8: nq_pad x 128 / nt_pad x 128 centred bytes; Qh/Th: n_pad x 128 halfs;
 // seeds: nt_pad (+ H_TT slack) 4-byte seeds in seed order.  Candidates: u8 route int (w << U8_SHIFT) | id, f16s
 // route float with the id in the low mantissa bits (keep_mask as on the f16 route).
-// group_rows: rows per candidate group (4, 8 or 16); ring: ring of 8 LDS tile buffers with counted waits instead of the
-// double-buffered form.
+// group_rows: rows per candidate group (4, 8 or 16); form: 0 / 1 two LDS tile buffers, 2 / 3 ring of 8 LDS tile buffers
+// with counted waits, 4 / 5 / 6 the register-operand forms (grid and splits sized for 128 queries per workgroup; 6: one
+// split per WAVE, grid.y = ceil(splits / 8)).
 int launch_coarse_u8(pm_ctx* ctx, const void* Q8, const void* T8, const int* seeds, int nq, int nq_pad, int nt, int splits,
-                     int tiles_per_split, int* cval, int slots, int group_rows, bool ring);
+                     int tiles_per_split, int* cval, int slots, int group_rows, int form);
 int launch_coarse_f16s(pm_ctx* ctx, const _Float16* Qh, const _Float16* Th, const float* seeds, int nq, int nq_pad, int nt,
                        int splits, int tiles_per_split, unsigned keep_mask, float* cval, int slots);
 

@@ -124,7 +124,8 @@ def test_seeded_forms_and_wave_layouts_same_result(ctx, oracle, nq, nt):
     assert_matches_equal(base[:128], oracle.bf_knn_l2(w["q"][:128], w["t"], 2, nthreads=8), "vs oracle")
 
 
-@pytest.mark.parametrize("nq,nt", [(700, 1000), (8192, 8192), (300, 20000), (257, 1153), (2048, 2048), (1500, 40000)])
+@pytest.mark.parametrize("nq,nt", [(700, 1000), (8192, 8192), (300, 20000), (257, 1153), (2048, 2048), (1500, 40000),
+                                   (16000, 16500), (8192, 32768)])       # the last two: long sweeps (the split-per-wave form is live)
 def test_u8_group_sizes_ring_and_refinements_same_result(ctx, oracle, nq, nt):
     """u8 route: rows per candidate group (4 / 8 / 16) x staging (two buffers / ring of eight with counted waits) x wave
     layout x refinement (integer on the byte copies / canonical f32): one result."""
@@ -133,9 +134,9 @@ def test_u8_group_sizes_ring_and_refinements_same_result(ctx, oracle, nq, nt):
     try:
         for group in (1, 2, 3):
             ctx.set_option(PM_OPT_KNN_U8_GROUP, group)
-            for ring in ((1, 2, 3) if group == 2 else (1,)):   # two buffers / ring + barrier per tile / ring + split-phase counters
+            for ring in ((1, 2, 3, 4, 5, 6) if group == 2 else (1,)):   # two buffers / ring + barrier per tile / ring + split-phase counters / operands from global memory
                 ctx.set_option(PM_OPT_KNN_RING, ring)
-                for waves in (0, 2, 3):                      # ring: 8 x 32 queries, 4 x 64, 16 x 32 (512-query workgroups)
+                for waves in ((0,) if ring >= 4 else (0, 2, 3)):   # ring: 8 x 32 queries, 4 x 64, 16 x 32 (512-query workgroups)
                     ctx.set_option(PM_OPT_KNN_F16_WAVES, waves)
                     for pro in ((0, 3, 8) if ring >= 2 and waves != 2 else (0,)):       # tiles requested before the sweep
                         ctx.set_option(PM_OPT_KNN_RING_PROLOGUE, pro)

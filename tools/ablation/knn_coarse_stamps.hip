@@ -66,9 +66,9 @@ int launch_coarse_i8(pm_ctx* ctx, const void* Qe, const void* Te, int nq, int nq
 }
 
 int launch_coarse_u8(pm_ctx* ctx, const void* Q8, const void* T8, const int* seeds, int nq, int nq_pad, int nt, int splits,
-                     int tiles_per_split, int* cval, int slots, int group_rows, bool ring)
+                     int tiles_per_split, int* cval, int slots, int group_rows, int form)
 {
-    return coarse_u8_dispatch<AblStamp>(ctx, Q8, T8, seeds, nq, nq_pad, nt, splits, tiles_per_split, cval, slots, group_rows, ring);
+    return coarse_u8_dispatch<AblStamp>(ctx, Q8, T8, seeds, nq, nq_pad, nt, splits, tiles_per_split, cval, slots, group_rows, form);
 }
 
 int launch_coarse_f16s(pm_ctx* ctx, const _Float16* Qh, const _Float16* Th, const float* seeds, int nq, int nq_pad, int nt,

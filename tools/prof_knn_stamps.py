@@ -60,3 +60,13 @@ show("last tile + final selection", 1 + ntl, 16)
 show("merge + store", 16, 17)
 xcc = s[:, 22] & 15
 print("workgroups per XCC:", np.bincount(xcc.astype(int), minlength=8).tolist())
+if any(o.startswith("12=") and int(o[3:]) >= 4 for o in opts):
+    print("register-operand form: wave 0's 5th..7th block (wait | ds_read+issue | MFMA chain issued | selection issued)")
+    for k in range(3):
+        b0 = 2 + 4 * k
+        show("  block %d: own pieces landed, A reads issued" % (4 + k), b0, b0 + 1)
+        show("  block %d: 16 MFMAs issued (incl. A data)" % (4 + k), b0 + 1, b0 + 2)
+        show("  block %d: selection issued" % (4 + k), b0 + 2, b0 + 3)
+        if k < 2:
+            show("  block %d end -> next block entry" % (4 + k), b0 + 3, b0 + 4)
+    show("whole sweep (entry -> done)", 1, 16)

@@ -17,7 +17,7 @@ d_q, d_t = torch.from_numpy(w["q"]).to(dev), torch.from_numpy(w["t"]).to(dev)
 d_out = torch.empty((nq, 2, 4), dtype=torch.int32, device=dev)
 names = ("knn_l2_prep", "knn_l2_mfma_u8", "knn_l2_mfma_f16s", "knn_l2_mfma_f16", "knn_l2_refine")
 res = {c: [] for c in cfgs}
-ALL = range(1, 17)
+ALL = range(1, 18)
 for rnd in range(5):
     for c in cfgs:
         for o in ALL:
