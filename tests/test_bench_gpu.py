@@ -30,7 +30,13 @@ def test_two_ranks_c3_shape(scaling):
     assert d["n_gpus"] == 2 and d["parity"] == "ok" and d["scaling"] == scaling
     assert d["ransac"]["n_matches"] > 300 and d["ransac"]["inliers"] > 100
     assert "ransac_fused" in d["kernels_us"] and "ransac_finish" in d["kernels_us"]
-    assert d["step_form"].startswith("pipelined") and d["ms_per_step"] == d["ms_per_step_pipelined"] and d["ms_per_step_serial"] > 0
+    # the form of the timed region is the one the warm-up trial found faster (max over ranks); both are reported
+    tr = d["step_form_trial"]
+    piped = tr["pipelined_ms_per_step"] < tr["serial_ms_per_step"]
+    assert d["step_form"].startswith("pipelined" if piped else "serial")
+    assert d["ms_per_step"] == (d["ms_per_step_pipelined"] if piped else d["ms_per_step_serial"])
+    assert d["ms_per_step_serial"] > 0 and d["ms_per_step_pipelined"] > 0
+    assert "timing_note" in d["config"]                   # two processes on one GPU: not performance data
     assert d["collectives"]["ranks"] == 2 and d["collectives"]["allgather_records_us"] > 0
 
 
