@@ -110,6 +110,8 @@ def bench_c5(args, world, rank, local_rank, dev, multi, saved_stdout):
     hold, jobs = build_jobs(args.c5_layout == "block")
     batch = pm.api.PairBatch(local_rank, args.lanes, n, n, dim)
     batch.set_option(pm.api.PM_OPT_RANSAC_PATH, args.ransac_path)
+    if args.ransac_wg_ids >= 0:
+        batch.set_option(pm.api.PM_OPT_RANSAC_WG_IDS, args.ransac_wg_ids)
     batch.set_desc_u8(u8)
     arr = batch.make_jobs(jobs)
     flags = pm.api.PM_KNN_HINT_U8
@@ -226,7 +228,7 @@ def main():
     ap.add_argument("--sustain-seconds", type=float, default=2.0,
                     help="after the K timed steps: back-to-back steps for at least this long (clock-sustained figure)")
     ap.add_argument("--pairs", type=int, default=256, help="c5: image pairs in the whole job")
-    ap.add_argument("--lanes", type=int, default=3, help="c5: streams (lanes) per GPU")
+    ap.add_argument("--lanes", type=int, default=6, help="c5: streams (lanes) per GPU")
     ap.add_argument("--c5-desc", default="f32", choices=["f32", "u8"],
                     help="c5: descriptor rows on the host: f32 (BASELINE's, the headline) or u8 (the same values as bytes: a quarter "
                          "of the link traffic, pm_batch_set_desc_type)")
@@ -238,6 +240,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="debugging: gloo lets a multi-rank run share ONE GPU (with --single-device); the driver uses nccl")
     ap.add_argument("--single-device", action="store_true", help="debugging: every rank uses cuda:0")
+    ap.add_argument("--ransac-wg-ids", type=int, default=-1,
+                    help="c5: hypothesis ids per RANSAC workgroup (-1: the batch's default, 32; 0: spread over all CUs)")
     ap.add_argument("--ransac-path", type=int, default=0, choices=[0, 1, 2],
                     help="A/B timing: PM_OPT_RANSAC_PATH (0 automatic, 1 solve + score launches, 2 one-launch kernel)")
     ap.add_argument("--hint", default="u8", choices=["u8", "int", "auto"],

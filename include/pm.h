@@ -119,7 +119,11 @@ enum {
     PM_OPT_KNN_PREP_ROWS  = 16, /* u8 route, prep kernel: 1 = 64 rows per workgroup, 2 = 16 rows per workgroup (default)         */
     PM_OPT_RANSAC_FORM    = 17, /* one-launch RANSAC kernel: 1 = correspondences in registers, two teams of four waves (round 2),
                                    2 = correspondences in LDS, one wave per hypothesis, 12 waves (default)           */
-    PM_OPT_COUNT_         = 18
+    PM_OPT_RANSAC_WG_IDS  = 18, /* one-launch RANSAC kernel: hypothesis ids per workgroup.  0 = automatic (ids spread over ALL
+                                   CUs: lowest latency for one run; a pm_batch lane defaults to 32 instead), 1 .. 128 = that
+                                   many: fewer, fuller workgroups, so the runs of several streams share the GPU — the fp64
+                                   solve costs a wave the same ~21k cycles whether 8 or 64 of its lanes are in use       */
+    PM_OPT_COUNT_         = 19
 };
 int  pm_ctx_set_option(pm_ctx* ctx, int option, int value);
 int  pm_ctx_get_option(pm_ctx* ctx, int option, int* value);

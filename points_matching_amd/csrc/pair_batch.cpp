@@ -68,6 +68,11 @@ int lane_init(Lane& L, int device, int max_n1, int max_n2, int dim)
 {
     int rc = pm_ctx_create(device, &L.ctx);
     if (rc != PM_OK) return rc;
+    // a batch is a throughput job: 32 ids per workgroup (64 workgroups at config C5's 2048 hypotheses) leave CUs to the other
+    // lanes' kernels instead of spreading 8 ids over each of the 256 CUs for the lowest latency of ONE run; the fp64 solve
+    // costs a wave the same ~21k cycles either way.  Measured (C5, u8 rows, 6 lanes): 31.0k -> 33.1k image pairs/s, with 3
+    // lanes 23.7k -> 28.7k; 64 ids lengthen each workgroup's scoring and measured slower (pm_batch_set_option overrides).
+    L.ctx->opts[PM_OPT_RANSAC_WG_IDS] = 32;
     const size_t n1 = static_cast<size_t>(max_n1), n2 = static_cast<size_t>(max_n2);
     {
         const size_t a = pm::align_up(sizeof(float) * n1 * dim, 256), b = pm::align_up(sizeof(float) * n2 * dim, 256);

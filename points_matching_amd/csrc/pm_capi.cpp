@@ -228,7 +228,7 @@ int pm_ctx_set_option(pm_ctx* ctx, int option, int value)
 {
     PM_REQUIRE(ctx != nullptr, PM_E_INVALID, "ctx is null");
     PM_REQUIRE(option >= 1 && option < PM_OPT_COUNT_, PM_E_INVALID, "unknown option");
-    const int vmax = option == PM_OPT_KNN_RING_PROLOGUE ? 8 : option == PM_OPT_KNN_RING ? 6 : (option == PM_OPT_KNN_F16_WAVES || option == PM_OPT_KNN_U8_GROUP) ? 3 : 2;
+    const int vmax = option == PM_OPT_RANSAC_WG_IDS ? 128 : option == PM_OPT_KNN_RING_PROLOGUE ? 8 : option == PM_OPT_KNN_RING ? 6 : (option == PM_OPT_KNN_F16_WAVES || option == PM_OPT_KNN_U8_GROUP) ? 3 : 2;
     PM_REQUIRE(value >= 0 && value <= vmax, PM_E_INVALID,
                "option value out of range (0 = automatic, 1, 2; KNN_F16_WAVES, KNN_U8_GROUP: .. 3)");
     ctx->opts[option] = value;

@@ -77,6 +77,8 @@ __global__ __launch_bounds__(RF_THREADS) void ransac_finish(pm_points_view v, co
 // and stretched the slowest workgroup's score phase from 17k to 25k cycles), at most RF_HB_MAX ids each.
 int fused_hb(const pm_ctx* ctx, long long nh)
 {
+    if (ctx->opts[PM_OPT_RANSAC_WG_IDS] > 0)                  // pinned (throughput form: a pm_batch lane asks for 64)
+        return ctx->opts[PM_OPT_RANSAC_WG_IDS] < RF_HB_MAX ? ctx->opts[PM_OPT_RANSAC_WG_IDS] : RF_HB_MAX;
     const long long wgs = ctx->n_cu;
     const long long per_round = wgs * RF_HB_MAX;
     const long long rounds = (nh + per_round - 1) / per_round;

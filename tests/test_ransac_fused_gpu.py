@@ -111,6 +111,24 @@ def test_device_resident_local_run_with_a_device_count(ctx, oracle, n, cap, H):
         assert int(d_ninl.item()) == ninl_o, path
 
 
+def test_ids_per_workgroup_option_same_bits(ctx, oracle):
+    """PM_OPT_RANSAC_WG_IDS (the throughput form a pm_batch lane uses: full solver waves, few workgroups): same result."""
+    n, H = 1500, 2048
+    x1, x2, _, _ = synth.two_view(n, seed=5, outlier_frac=0.35, noise_px=0.6)
+    want = oracle.ransac_fundamental(x1, x2, H, 1.0, 0xC5, nthreads=8)
+    try:
+        for form in (2, 1):
+            ctx.set_option(pm.api.PM_OPT_RANSAC_FORM, form)
+            for ids in (0, 1, 7, 64, 100, 128):
+                ctx.set_option(pm.api.PM_OPT_RANSAC_WG_IDS, ids)
+                got = ctx.ransac_fundamental(x1, x2, H, 1.0, 0xC5)
+                assert got[4] == want[4] and got[3] == want[3] and (got[2] == want[2]).all(), (form, ids)
+                assert (got[1].view(np.uint64) == want[1].view(np.uint64)).all(), (form, ids)
+    finally:
+        ctx.set_option(pm.api.PM_OPT_RANSAC_FORM, 0)
+        ctx.set_option(pm.api.PM_OPT_RANSAC_WG_IDS, 0)
+
+
 def test_many_hypotheses_and_every_register_depth(ctx, oracle):
     """100 000 ids (four rounds of workgroups, ids beyond 2^31) on each point-slot depth of the kernel."""
     for n in (900, 2400, 5000, 9175):
