@@ -112,6 +112,7 @@ def bench_c5(args, world, rank, local_rank, dev, multi, saved_stdout):
     batch.set_option(pm.api.PM_OPT_RANSAC_PATH, args.ransac_path)
     if args.ransac_wg_ids >= 0:
         batch.set_option(pm.api.PM_OPT_RANSAC_WG_IDS, args.ransac_wg_ids)
+    batch.set_host_threads(args.c5_host_threads)
     batch.set_desc_u8(u8)
     arr = batch.make_jobs(jobs)
     flags = pm.api.PM_KNN_HINT_U8
@@ -240,6 +241,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="debugging: gloo lets a multi-rank run share ONE GPU (with --single-device); the driver uses nccl")
     ap.add_argument("--single-device", action="store_true", help="debugging: every rank uses cuda:0")
+    ap.add_argument("--c5-host-threads", type=int, default=0, choices=[0, 1, 2],
+                    help="c5: host threads enqueueing the pairs (0: automatic = 2 with >= 4 lanes)")
     ap.add_argument("--ransac-wg-ids", type=int, default=-1,
                     help="c5: hypothesis ids per RANSAC workgroup (-1: the batch's default, 32; 0: spread over all CUs)")
     ap.add_argument("--ransac-path", type=int, default=0, choices=[0, 1, 2],

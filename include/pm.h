@@ -424,6 +424,9 @@ int pm_batch_set_option(pm_batch* b, int option, int value);     /* pm_ctx_set_o
  * (desc2 16-byte, keypoints 8-byte aligned relative to desc1, at most 768 bytes of padding in all), the pair is sent
  * in one copy instead of four — detected per job, nothing to declare. */
 int pm_batch_set_desc_type(pm_batch* b, int desc_u8);
+/* Host threads that enqueue the pairs of one pm_batch_run call: 0 = automatic (two when the batch has >= 4 lanes: each
+ * thread owns half of the lanes and every second job), 1 = the calling thread only, 2.  Results are in job order either way. */
+int pm_batch_set_host_threads(pm_batch* b, int n);
 int pm_batch_run(pm_batch* b, const pm_pair_job* jobs, int n_jobs, float ratio, int knn_flags,
                  const pm_ransac_params* p, pm_pair_result* results, pm_match* good, uint8_t* masks);
 /* Page-lock / release a caller-owned host buffer (hipHostRegister) so the batch copies overlap. */

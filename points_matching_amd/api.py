@@ -42,7 +42,7 @@ EXPORTS = [
     "pm_mgpu_create", "pm_mgpu_destroy", "pm_mgpu_size", "pm_mgpu_ctx", "pm_mgpu_ransac_fundamental", "pm_mgpu_match_ransac",
     "pm_mgpu_lane_ctx", "pm_mgpu_set_lanes", "pm_mgpu_set_train", "pm_mgpu_set_train_dev", "pm_mgpu_submit_dev", "pm_mgpu_collect",
     "pm_mgpu_allgather_latency", "pm_mgpu_batch_run", "pm_mgpu_batch_set_option",
-    "pm_batch_create", "pm_batch_destroy", "pm_batch_run", "pm_batch_set_option", "pm_batch_set_desc_type",
+    "pm_batch_create", "pm_batch_destroy", "pm_batch_run", "pm_batch_set_option", "pm_batch_set_desc_type", "pm_batch_set_host_threads",
     "pm_bf_knn_l2_u8", "pm_bf_knn_l2_u8_dev", "pm_bf_knn_l2_u8_ratio_dev", "pm_host_register", "pm_host_unregister",
     "pm_lmeds_fundamental", "pm_lmeds_fundamental_dev", "pm_lmeds_default_iters", "pm_ransac7_adaptive",
     "pm_epipolar_residuals", "pm_f_scale_f33", "pm_epilines", "pm_epiline_endpoints",
@@ -503,6 +503,10 @@ class PairBatch:
     def set_desc_u8(self, on=True):
         """the jobs' desc1 / desc2 point at uint8 rows"""
         _check(lib().pm_batch_set_desc_type(self._h, int(bool(on))))
+
+    def set_host_threads(self, n):
+        """0 = automatic (two host threads with >= 4 lanes), 1, 2"""
+        _check(lib().pm_batch_set_host_threads(self._h, int(n)))
 
     @staticmethod
     def make_jobs(jobs):

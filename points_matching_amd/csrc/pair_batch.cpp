@@ -8,6 +8,7 @@
 // kernels of neighbouring pairs fill each other's tails.  The host thread only enqueues; it waits
 // for a lane when that lane's previous pair has to hand back its result slot.
 #include <new>
+#include <thread>
 
 #include "pm_common.hpp"
 
@@ -44,6 +45,7 @@ struct Lane {
 struct pm_batch {
     int device = 0, n_lanes = 0, max_n1 = 0, max_n2 = 0, dim = 0;
     int desc_u8 = 0;              // pm_batch_set_desc_type: the jobs' descriptor rows are bytes
+    int host_threads = 0;         // 0: automatic (two with >= 4 lanes), 1: the calling thread only
     Lane* lanes = nullptr;
 };
 
@@ -115,65 +117,10 @@ int lane_collect(pm_batch* b, Lane& L, pm_pair_result* results, pm_match* good, 
     return PM_OK;
 }
 
-}  // namespace
-
-extern "C" int pm_batch_create(int device, int n_lanes, int max_n1, int max_n2, int dim, pm_batch** out)
+// jobs j = t mod T of one pm_batch_run call, on lanes t, t + T, ... (one host thread)
+int run_part(pm_batch* b, const pm_pair_job* jobs, int n_jobs, int t, int T, float ratio, int knn_flags, const pm_ransac_params* p,
+             pm_pair_result* results, pm_match* good, uint8_t* masks)
 {
-    PM_REQUIRE(out != nullptr, PM_E_INVALID, "out is null");
-    PM_REQUIRE(n_lanes >= 1 && n_lanes <= 16 && max_n1 >= 1 && max_n2 >= 1 && dim >= 1, PM_E_INVALID,
-               "need 1 <= n_lanes <= 16, max_n1, max_n2, dim >= 1");
-    PM_HIP_CHECK(hipSetDevice(device));
-    pm_batch* b = new (std::nothrow) pm_batch;
-    PM_REQUIRE(b != nullptr, PM_E_NOMEM, "out of host memory");
-    b->device = device; b->n_lanes = n_lanes; b->max_n1 = max_n1; b->max_n2 = max_n2; b->dim = dim;
-    b->lanes = new (std::nothrow) Lane[n_lanes];
-    if (!b->lanes) { delete b; pm::set_error("out of host memory"); return PM_E_NOMEM; }
-    for (int i = 0; i < n_lanes; ++i) {
-        const int rc = lane_init(b->lanes[i], device, max_n1, max_n2, dim);
-        if (rc != PM_OK) { (void)pm_batch_destroy(b); return rc; }
-    }
-    *out = b;
-    return PM_OK;
-}
-
-extern "C" int pm_batch_set_option(pm_batch* b, int option, int value)
-{
-    PM_REQUIRE(b != nullptr, PM_E_INVALID, "batch is null");
-    for (int i = 0; i < b->n_lanes; ++i) {
-        const int rc = pm_ctx_set_option(b->lanes[i].ctx, option, value);
-        if (rc != PM_OK) return rc;
-    }
-    return PM_OK;
-}
-
-extern "C" int pm_batch_set_desc_type(pm_batch* b, int desc_u8)
-{
-    PM_REQUIRE(b != nullptr && (desc_u8 == 0 || desc_u8 == 1), PM_E_INVALID, "descriptor type: 0 = float32 rows, 1 = uint8 rows");
-    b->desc_u8 = desc_u8;
-    return PM_OK;
-}
-
-extern "C" int pm_batch_destroy(pm_batch* b)
-{
-    if (!b) return PM_OK;
-    (void)hipSetDevice(b->device);
-    for (int i = 0; i < b->n_lanes; ++i) lane_free(b->lanes[i]);
-    delete[] b->lanes;
-    delete b;
-    return PM_OK;
-}
-
-extern "C" int pm_batch_run(pm_batch* b, const pm_pair_job* jobs, int n_jobs, float ratio, int knn_flags,
-                            const pm_ransac_params* p, pm_pair_result* results, pm_match* good, uint8_t* masks)
-{
-    PM_REQUIRE(b != nullptr && p != nullptr, PM_E_INVALID, "null batch / params");
-    PM_REQUIRE(n_jobs >= 0 && (n_jobs == 0 || (jobs && results)), PM_E_INVALID, "null jobs / results");
-    for (int j = 0; j < n_jobs; ++j) {
-        const pm_pair_job& jb = jobs[j];
-        PM_REQUIRE(jb.n1 >= 1 && jb.n1 <= b->max_n1 && jb.n2 >= 1 && jb.n2 <= b->max_n2, PM_E_INVALID,
-                   "a pair exceeds the batch's max_n1 / max_n2 (or is empty)");
-        PM_REQUIRE(jb.desc1 && jb.desc2 && jb.kp1_xy && jb.kp2_xy, PM_E_INVALID, "null pointer in a pair job");
-    }
     PM_HIP_CHECK(hipSetDevice(b->device));
     int rc = PM_OK;
     // A failing HIP call must not leave the loop by `return`: copies may still be in flight on the caller's buffers
@@ -186,8 +133,9 @@ extern "C" int pm_batch_run(pm_batch* b, const pm_pair_job* jobs, int n_jobs, fl
             rc = PM_E_HIP;                                                                     \
         }                                                                                      \
     } while (0)
-    for (int j = 0; j < n_jobs && rc == PM_OK; ++j) {
-        Lane& L = b->lanes[j % b->n_lanes];
+    const int lanes_mine = (b->n_lanes - t + T - 1) / T;          // lanes t, t + T, ...
+    for (int j = t, c = 0; j < n_jobs && rc == PM_OK; j += T, ++c) {
+        Lane& L = b->lanes[t + T * (c % lanes_mine)];
         rc = lane_collect(b, L, results, good, masks);
         if (rc != PM_OK) break;
         const pm_pair_job& jb = jobs[j];
@@ -239,11 +187,101 @@ extern "C" int pm_batch_run(pm_batch* b, const pm_pair_job* jobs, int n_jobs, fl
     }
 #undef PM_BATCH_HIP
     // drain in job order (also after an error: nothing may stay in flight on the caller's buffers)
-    for (int i = 0; i < b->n_lanes; ++i) {
+    for (int i = t; i < b->n_lanes; i += T) {
         if (rc == PM_OK) rc = lane_collect(b, b->lanes[i], results, good, masks);
         else { (void)hipStreamSynchronize(b->lanes[i].ctx->stream); b->lanes[i].pending = -1; }
     }
     return rc;
+}
+
+
+}  // namespace
+
+extern "C" int pm_batch_create(int device, int n_lanes, int max_n1, int max_n2, int dim, pm_batch** out)
+{
+    PM_REQUIRE(out != nullptr, PM_E_INVALID, "out is null");
+    PM_REQUIRE(n_lanes >= 1 && n_lanes <= 16 && max_n1 >= 1 && max_n2 >= 1 && dim >= 1, PM_E_INVALID,
+               "need 1 <= n_lanes <= 16, max_n1, max_n2, dim >= 1");
+    PM_HIP_CHECK(hipSetDevice(device));
+    pm_batch* b = new (std::nothrow) pm_batch;
+    PM_REQUIRE(b != nullptr, PM_E_NOMEM, "out of host memory");
+    b->device = device; b->n_lanes = n_lanes; b->max_n1 = max_n1; b->max_n2 = max_n2; b->dim = dim;
+    b->lanes = new (std::nothrow) Lane[n_lanes];
+    if (!b->lanes) { delete b; pm::set_error("out of host memory"); return PM_E_NOMEM; }
+    for (int i = 0; i < n_lanes; ++i) {
+        const int rc = lane_init(b->lanes[i], device, max_n1, max_n2, dim);
+        if (rc != PM_OK) { (void)pm_batch_destroy(b); return rc; }
+    }
+    *out = b;
+    return PM_OK;
+}
+
+extern "C" int pm_batch_set_option(pm_batch* b, int option, int value)
+{
+    PM_REQUIRE(b != nullptr, PM_E_INVALID, "batch is null");
+    for (int i = 0; i < b->n_lanes; ++i) {
+        const int rc = pm_ctx_set_option(b->lanes[i].ctx, option, value);
+        if (rc != PM_OK) return rc;
+    }
+    return PM_OK;
+}
+
+extern "C" int pm_batch_set_host_threads(pm_batch* b, int n)
+{
+    PM_REQUIRE(b != nullptr && n >= 0 && n <= 2, PM_E_INVALID, "host threads: 0 = automatic, 1, 2");
+    b->host_threads = n;
+    return PM_OK;
+}
+
+extern "C" int pm_batch_set_desc_type(pm_batch* b, int desc_u8)
+{
+    PM_REQUIRE(b != nullptr && (desc_u8 == 0 || desc_u8 == 1), PM_E_INVALID, "descriptor type: 0 = float32 rows, 1 = uint8 rows");
+    b->desc_u8 = desc_u8;
+    return PM_OK;
+}
+
+extern "C" int pm_batch_destroy(pm_batch* b)
+{
+    if (!b) return PM_OK;
+    (void)hipSetDevice(b->device);
+    for (int i = 0; i < b->n_lanes; ++i) lane_free(b->lanes[i]);
+    delete[] b->lanes;
+    delete b;
+    return PM_OK;
+}
+
+extern "C" int pm_batch_run(pm_batch* b, const pm_pair_job* jobs, int n_jobs, float ratio, int knn_flags,
+                            const pm_ransac_params* p, pm_pair_result* results, pm_match* good, uint8_t* masks)
+{
+    PM_REQUIRE(b != nullptr && p != nullptr, PM_E_INVALID, "null batch / params");
+    PM_REQUIRE(n_jobs >= 0 && (n_jobs == 0 || (jobs && results)), PM_E_INVALID, "null jobs / results");
+    for (int j = 0; j < n_jobs; ++j) {
+        const pm_pair_job& jb = jobs[j];
+        PM_REQUIRE(jb.n1 >= 1 && jb.n1 <= b->max_n1 && jb.n2 >= 1 && jb.n2 <= b->max_n2, PM_E_INVALID,
+                   "a pair exceeds the batch's max_n1 / max_n2 (or is empty)");
+        PM_REQUIRE(jb.desc1 && jb.desc2 && jb.kp1_xy && jb.kp2_xy, PM_E_INVALID, "null pointer in a pair job");
+    }
+    // Host threads: enqueueing a pair costs the host ~30 us (copies + five launches + the event), which at config C5's u8
+    // rows is what bounds the batch once the GPU work per pair is ~20 us.  With >= 4 lanes the jobs are dealt to TWO host
+    // threads, each with its own half of the lanes (thread t: jobs j = t mod T on lanes t, t + T, ...): nothing is shared
+    // but the device.  Results land in job order either way.
+    const int T = (b->n_lanes >= 4 && n_jobs >= 16 && b->host_threads != 1) ? 2 : 1;
+    int rcs[2] = {PM_OK, PM_OK};
+    char errs[2][256] = {"", ""};
+    auto work = [&](int t) {
+        rcs[t] = run_part(b, jobs, n_jobs, t, T, ratio, knn_flags, p, results, good, masks);
+        if (rcs[t] != PM_OK) snprintf(errs[t], sizeof errs[t], "%s", pm_last_error());     // (the error text is per thread)
+    };
+    if (T == 1) {
+        work(0);
+    } else {
+        std::thread other(work, 1);
+        work(0);
+        other.join();
+    }
+    for (int t = 0; t < T; ++t)
+        if (rcs[t] != PM_OK) { pm::set_error("%s", errs[t]); return rcs[t]; }
+    return PM_OK;
 }
 
 extern "C" int pm_host_register(void* ptr, size_t bytes)

@@ -57,6 +57,28 @@ def test_batch_matches_oracle_pair_by_pair(oracle, lanes):
     b.close()
 
 
+def test_batch_two_host_threads_same_results_in_job_order():
+    """>= 4 lanes and >= 16 jobs: two host threads enqueue (each its own half of the lanes, every second job).  Results in job
+    order, identical to the one-thread, one-lane run."""
+    ws = _pairs() * 3                                            # 21 jobs
+    max1, max2 = max(s[0] for s in SIZES), max(s[1] for s in SIZES)
+    jobs = [(w["q"].ctypes.data, w["q"].shape[0], w["t"].ctypes.data, w["t"].shape[0], w["kp1"].ctypes.data, w["kp2"].ctypes.data) for w in ws]
+    b1 = pm.api.PairBatch(0, 1, max1, max2, 128)
+    want, g_w, m_w = b1.run(jobs, RATIO, H, TAU, SEED, want_good=True, want_masks=True)
+    b1.close()
+    for lanes, threads in ((5, 0), (4, 2), (6, 1)):
+        b = pm.api.PairBatch(0, lanes, max1, max2, 128)
+        b.set_host_threads(threads)
+        for rep in range(2):
+            got, g_g, m_g = b.run(jobs, RATIO, H, TAU, SEED, want_good=True, want_masks=True)
+            for j in range(len(ws)):
+                assert (got[j].status, got[j].best_key, got[j].n_good, got[j].n_inliers, bytes(got[j].F)) == \
+                       (want[j].status, want[j].best_key, want[j].n_good, want[j].n_inliers, bytes(want[j].F)), (lanes, threads, rep, j)
+                ng = want[j].n_good
+                assert (g_g[j, :ng] == g_w[j, :ng]).all() and (m_g[j] == m_w[j]).all(), (lanes, threads, rep, j)
+        b.close()
+
+
 def test_batch_pinned_inputs_and_argument_checks():
     w = synth.pair_workload(nq=256, nt=256, dim=128, seed=3, planted=0.5)
     bufs = [w["q"], w["t"], w["kp1"], w["kp2"]]
