@@ -1489,6 +1489,7 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
     const bool fast = !(flags & PM_KNN_FORCE_EXACT) && (k <= 2 || (k <= 4 && ctx->opts[PM_OPT_KNN_WIDE] != 1)) && dim <= 256 &&
                       nt >= 1 && (narrow || wide16) && (dim >= 4 || !vec);
     if (!fast) {
+        if (u8in) return 2;                                  // (u8 rows have no f32 image here: the caller widens first)
         const int rx = run_exact(ctx, dq, nq, dt, nt, dim, k, dout);
         return rx == PM_OK && fuse ? 1 : rx;                 // 1: done, but the caller still has to filter
     }

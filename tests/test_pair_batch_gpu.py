@@ -176,3 +176,10 @@ def test_knn_l2_u8_rows_equal_the_f32_matcher(ctx, oracle, nq, nt, dim, k):
     want = oracle.bf_knn_l2(q.astype(np.float32), t.astype(np.float32), k, nthreads=8)
     from util import assert_matches_equal
     assert_matches_equal(ctx.bf_knn_l2_u8(q, t, k), want, "u8 rows %s" % ((nq, nt, dim, k),))
+    # every option that sends a shape to the exact kernel must first widen u8 rows (found by tools/fuzz_campaign.py: k = 3 with
+    # PM_OPT_KNN_WIDE = 1 reached the f32 kernel with the null f32 pointers of the u8 entry point)
+    try:
+        ctx.set_option(pm.api.PM_OPT_KNN_WIDE, 1)
+        assert_matches_equal(ctx.bf_knn_l2_u8(q, t, k), want, "u8 rows, exact kernel for k > 2 %s" % ((nq, nt, dim, k),))
+    finally:
+        ctx.set_option(pm.api.PM_OPT_KNN_WIDE, 0)

@@ -24,14 +24,20 @@ rng = np.random.default_rng(seed)
 t_end = time.time() + budget
 counts = {"l2": 0, "hamming": 0, "ransac": 0, "lmeds": 0}
 NT = 16
+TRACE = bool(os.environ.get("PM_FUZZ_TRACE"))      # print every GPU call before it is made (a GPU fault names no case)
+
+
+def trace(*a):
+    if TRACE:
+        print("  >", *a, flush=True)
 
 
 def l2_case(i):
-    dim = int(rng.choice([4, 8, 12, 16, 20, 32, 36, 64, 96, 100, 128, 128, 128, 128]))
-    big = rng.random() < 0.15
+    dim = int(rng.choice([4, 5, 7, 8, 12, 16, 20, 32, 36, 64, 96, 100, 128, 128, 128, 128, 128, 130, 200, 256]))
+    big = rng.random() < 0.15 and dim <= 128
     nq = int(rng.integers(1, 12000 if big else 2500))
     nt = int(rng.integers(1, 40000 if big else 6000))
-    k = int(rng.choice([1, 2, 2]))
+    k = int(rng.choice([1, 2, 2, 2, 3, 4, 5]))
     kind = str(rng.choice(["sift", "surf"]))
     q, t, _ = (synth.sift_like if kind == "sift" else synth.surf_like)(nq, nt, dim, seed=int(rng.integers(1 << 30)))
     twist = int(rng.integers(0, 9))
@@ -58,16 +64,29 @@ def l2_case(i):
         q = np.abs(q) * np.float32(255.0 / max(1e-9, np.abs(q).max())); q = np.rint(q)   # integers in float queries only
     want = O.bf_knn_l2(q, t, k, nthreads=NT)
     opts = {}
-    if rng.random() < 0.3:
+    if rng.random() < 0.4:
         opts = {A.PM_OPT_KNN_F16_WAVES: int(rng.integers(0, 4)), A.PM_OPT_KNN_STAGING: int(rng.integers(0, 3)),
                 A.PM_OPT_KNN_XCD_TILE: int(rng.integers(0, 3)), A.PM_OPT_KNN_WG_PER_CU: int(rng.integers(0, 3)),
-                A.PM_OPT_KNN_GENERAL_F16: int(rng.integers(0, 3))}
+                A.PM_OPT_KNN_GENERAL_F16: int(rng.integers(0, 3)),
+                # round 3: seeded f16 form, u8 group size / coarse-kernel form / refinement, wide-dim passes, prep geometry
+                A.PM_OPT_KNN_SEEDED: int(rng.integers(0, 3)), A.PM_OPT_KNN_U8_GROUP: int(rng.integers(0, 4)),
+                A.PM_OPT_KNN_RING: int(rng.integers(0, 7)), A.PM_OPT_KNN_U8_REFINE: int(rng.integers(0, 3)),
+                A.PM_OPT_KNN_RING_PROLOGUE: int(rng.integers(0, 9)), A.PM_OPT_KNN_WIDE: int(rng.integers(0, 3)),
+                A.PM_OPT_KNN_PREP_ROWS: int(rng.integers(0, 3))}
+    u8_valued = q.size and t.size and q.min() >= 0 and q.max() <= 255 and t.min() >= 0 and t.max() <= 255 and \
+        bool((q == np.rint(q)).all()) and bool((t == np.rint(t)).all())
     try:
         for o, v in opts.items():
             ctx.set_option(o, v)
-        for flags in (0, A.PM_KNN_HINT_INTEGER, A.PM_KNN_FORCE_F32):
+        for flags in (0, A.PM_KNN_HINT_INTEGER, A.PM_KNN_FORCE_F32, A.PM_KNN_HINT_U8):
+            trace("l2", i, kind, nq, nt, dim, "k", k, "twist", twist, "flags", flags, opts)
             assert_matches_equal(ctx.bf_knn_l2(q, t, k, flags), want,
                                  "L2 case %d: %s %dx%dx%d k=%d twist=%d flags=%d opts=%s" % (i, kind, nq, nt, dim, k, twist, flags, opts))
+        if u8_valued:                                     # the same values as uint8 rows (pm_bf_knn_l2_u8)
+            trace("l2 u8 rows", i, nq, nt, dim, "k", k, opts)
+            assert_matches_equal(ctx.bf_knn_l2_u8(q.astype(np.uint8), t.astype(np.uint8), k), want,
+                                 "L2 case %d (u8 rows): %dx%dx%d k=%d twist=%d opts=%s" % (i, nq, nt, dim, k, twist, opts))
+            counts["l2_u8_rows"] = counts.get("l2_u8_rows", 0) + 1
     finally:
         for o in opts:
             ctx.set_option(o, 0)
@@ -88,6 +107,7 @@ def hamming_case(i):
     route = int(rng.integers(0, 3))
     try:
         ctx.set_option(A.PM_OPT_HAMMING_ROUTE, route)
+        trace("hamming", i, nq, nt, nbytes, "k", k, "route", route)
         assert_matches_equal(ctx.bf_knn_hamming(q, t, k), O.bf_knn_hamming(q, t, k, nthreads=NT),
                              "Hamming case %d: %dx%d bytes=%d k=%d route=%d" % (i, nq, nt, nbytes, k, route))
     finally:
@@ -117,13 +137,20 @@ def ransac_case(i):
     elif tw == 3 and n >= 8:
         x1[:, 1] = 3.0                                      # collinear points in image 1
     path = int(rng.integers(0, 3))
+    form = int(rng.integers(0, 3))                           # one-launch kernel: automatic / register tiles / LDS tile
+    ids = int(rng.choice([0, 0, int(rng.integers(1, 129))]))  # hypothesis ids per workgroup
     try:
         ctx.set_option(A.PM_OPT_RANSAC_PATH, path)
+        ctx.set_option(A.PM_OPT_RANSAC_FORM, form)
+        ctx.set_option(A.PM_OPT_RANSAC_WG_IDS, ids)
+        trace("ransac", i, "n", n, "iters", iters, "hb", hb, "thr", thr, "kind", kind, "tw", tw, "path", path, "form", form, "ids", ids)
         got = ctx.ransac_fundamental(x1, x2, hb + iters, thr, int(rng.integers(1 << 31)) if False else 77 + i, kind, hyp_begin=hb)
         want = O.ransac_fundamental(x1, x2, hb + iters, thr, 77 + i, kind, hyp_begin=hb, nthreads=NT)
-        same_ransac(got, want, "RANSAC case %d: n=%d iters=%d hb=%d thr=%g kind=%d tw=%d path=%d" % (i, n, iters, hb, thr, kind, tw, path))
+        same_ransac(got, want, "RANSAC case %d: n=%d iters=%d hb=%d thr=%g kind=%d tw=%d path=%d form=%d ids=%d" % (i, n, iters, hb, thr, kind, tw, path, form, ids))
     finally:
         ctx.set_option(A.PM_OPT_RANSAC_PATH, 0)
+        ctx.set_option(A.PM_OPT_RANSAC_FORM, 0)
+        ctx.set_option(A.PM_OPT_RANSAC_WG_IDS, 0)
 
 
 def lmeds_case(i):
@@ -131,6 +158,7 @@ def lmeds_case(i):
     iters = int(rng.integers(1, 600))
     x1, x2, _, _ = synth.two_view(n, seed=int(rng.integers(1 << 30)), outlier_frac=float(rng.uniform(0, 0.45)),
                                   noise_px=float(rng.uniform(0, 1.5)))
+    trace("lmeds", i, n, iters)
     got = A.lmeds_fundamental(ctx, x1, x2, iters, 5 + i)
     want = O.lmeds_fundamental(x1, x2, iters, 5 + i, nthreads=NT)
     what = "LMedS case %d: n=%d iters=%d" % (i, n, iters)
@@ -149,7 +177,7 @@ def pipeline_case(i):
     nq = int(rng.integers(8, 3000)); nt = int(rng.integers(2, 4000))
     kind = str(rng.choice(["sift", "surf"]))
     w = synth.pair_workload(nq, nt, dim, seed=int(rng.integers(1 << 30)), planted=float(rng.uniform(0.05, 0.6)), kind=kind)
-    flags = int(rng.choice([0, A.PM_KNN_HINT_INTEGER])) if kind == "sift" else 0
+    flags = int(rng.choice([0, A.PM_KNN_HINT_INTEGER, A.PM_KNN_HINT_U8, A.PM_KNN_HINT_U8])) if kind == "sift" else 0
     ratio = float(rng.choice([0.6, 0.8, 0.95]))
     mode = int(rng.integers(0, 3)); with_knn = bool(rng.integers(0, 2)) or mode == 1
     H = int(rng.integers(1, 1500))
@@ -163,6 +191,7 @@ def pipeline_case(i):
     d_key = torch.zeros(1, dtype=torch.int64, device=dev); d_F = torch.zeros(9, dtype=torch.float64, device=dev)
     d_mask = torch.zeros(nq, dtype=torch.uint8, device=dev); d_ninl = torch.zeros(1, dtype=torch.int32, device=dev)
     what = "pipeline case %d: %s %dx%dx%d flags=%d ratio=%g fusion=%d knn=%d H=%d" % (i, kind, nq, nt, dim, flags, ratio, mode, with_knn, H)
+    trace(what)
     try:
         ctx.set_option(A.PM_OPT_FILTER_FUSION, mode)
         ctx.bf_knn_l2_ratio_dev(d_q.data_ptr(), nq, d_t.data_ptr(), nt, dim, flags, ratio, d_kp1.data_ptr(), d_kp2.data_ptr(),
