@@ -123,7 +123,10 @@ enum {
                                    CUs: lowest latency for one run; a pm_batch lane defaults to 32 instead), 1 .. 128 = that
                                    many: fewer, fuller workgroups, so the runs of several streams share the GPU — the fp64
                                    solve costs a wave the same ~21k cycles whether 8 or 64 of its lanes are in use       */
-    PM_OPT_COUNT_         = 19
+    PM_OPT_HAMMING_REFINE = 19, /* Hamming matrix-core route, refinement: 1 = one wave per query (default), 2 = four queries per
+                                   wave, one 16-lane row each (<= 64 candidate entries per query; measured 4x slower at
+                                   config C4: tie-heavy integer distances make whole-sub-list scans common)            */
+    PM_OPT_COUNT_         = 20
 };
 int  pm_ctx_set_option(pm_ctx* ctx, int option, int value);
 int  pm_ctx_get_option(pm_ctx* ctx, int option, int* value);

@@ -82,6 +82,7 @@ PM_OPT_KNN_WIDE = 15
 PM_OPT_KNN_PREP_ROWS = 16
 PM_OPT_RANSAC_FORM = 17
 PM_OPT_RANSAC_WG_IDS = 18
+PM_OPT_HAMMING_REFINE = 19
 
 
 _lib = None

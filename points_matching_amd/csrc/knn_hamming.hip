@@ -371,6 +371,129 @@ __global__ __launch_bounds__(256) void knn_hamming_refine(const uint32_t* __rest
     }
 }
 
+// Round 3 (built, measured SLOWER at config C4, kept behind PM_OPT_HAMMING_REFINE = 2: see run_mfma):
+// FOUR queries per wave, one 16-lane row each (the form of knn_l2_refine8): at config C4 a query has 32 candidate
+// entries, half a wave; the k-th-smallest search and the final top-k become 4-step DPP reductions inside a row (row_ror,
+// no v_readlane), the instruction stream of a wave serves four queries.  Same entry layout, same tau / full-sub-list /
+// candidate rules and therefore the same rows evaluated as knn_hamming_refine above; for slots <= 64 (NE = 1, 2 or 4
+// entries per lane: entry e = l + 16*i).
+__device__ __forceinline__ unsigned row16_min_u32(unsigned v)
+{
+    v = min(v, pm::dpp_u32<0x121>(v));      // row_ror:1
+    v = min(v, pm::dpp_u32<0x122>(v));
+    v = min(v, pm::dpp_u32<0x124>(v));
+    v = min(v, pm::dpp_u32<0x128>(v));
+    return v;
+}
+__device__ __forceinline__ unsigned long long row16_min_u64(unsigned long long v)
+{
+    const unsigned hi = static_cast<unsigned>(v >> 32), lo = static_cast<unsigned>(v);
+    const unsigned mh = row16_min_u32(hi);
+    const unsigned ml = row16_min_u32(hi == mh ? lo : 0xFFFFFFFFu);
+    return (static_cast<unsigned long long>(mh) << 32) | ml;
+}
+__device__ __forceinline__ unsigned row16_min(unsigned v) { return row16_min_u32(v); }
+__device__ __forceinline__ unsigned long long row16_min(unsigned long long v) { return row16_min_u64(v); }
+
+template <int NE, typename K>
+__global__ __launch_bounds__(256) void knn_hamming_refine4(const uint32_t* __restrict__ Q, const uint32_t* __restrict__ T,
+                                                           int nq, int nt, int k, const int* __restrict__ cand,
+                                                           int slots, int tiles_per_split, int shift,
+                                                           pm_match* __restrict__ out)
+{
+    __shared__ int clist[4][4][16 * NE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qi = lane >> 4, l = lane & 15;
+    const int q = blockIdx.x * 16 + wave * 4 + qi;
+    const bool live = q < nq;
+    const int qc = live ? q : nq - 1;                        // rows past the last query shadow it (DPP rows stay whole)
+    const uint4* qr = reinterpret_cast<const uint4*>(Q + static_cast<size_t>(qc) * 8);
+    const uint4 q0 = qr[0], q1 = qr[1];
+    const int gmask = (1 << shift) - 1;
+    auto row_bits = [&](bool p) { return static_cast<unsigned>(__ballot(p) >> (16 * qi)) & 0xFFFFu; };
+
+    int v[NE], dc[NE];
+    bool whole[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = l + 16 * i;
+        v[i] = e < slots ? cand[static_cast<size_t>(qc) * slots + e] : I8_EMPTY;
+        dc[i] = v[i] == I8_EMPTY ? 0x7FFFFFF0 : ((I8_BITS - (v[i] >> shift)) >> 1);
+        const int gid2 = v[i] & gmask, gid = gid2 >> 1, split = e >> 3;
+        const int last = (split * tiles_per_split + (gid >> 3)) * H_TT + 32 * ((gid >> 1) & 3) + 16 * (gid & 1) +
+                         4 * (gid2 & 1) + 11;
+        whole[i] = v[i] != I8_EMPTY && last < nt;
+    }
+    unsigned lastk = 0u;
+    int tau = 0;
+    for (int c = 0; c < k; ++c) {
+        unsigned m = 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const unsigned dt = whole[i] ? static_cast<unsigned>(dc[i]) : 0x7FFFu;
+            const unsigned key = (dt << 16) | static_cast<unsigned>(l + 16 * i);
+            if ((c == 0 || key > lastk) && key < m) m = key;
+        }
+        m = row16_min_u32(m);
+        lastk = m;
+        tau = static_cast<int>(m >> 16);
+    }
+    if (tau == 0x7FFF) tau = 0x7FFFFFFF;
+    Best2<typename K::type> best{K::NONE, K::NONE};
+    int total = 0;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        if (16 * i >= slots) break;                          // wave-uniform
+        const bool within = v[i] != I8_EMPTY && dc[i] <= tau;
+        const unsigned full = row_bits(within && (l & 3) == 3);
+        const bool my_full = (full >> (l | 3)) & 1u;
+        const unsigned cm = row_bits(within && !my_full);
+        if (within && !my_full) clist[wave][qi][total + __popc(cm & ((1u << l) - 1u))] = (v[i] & gmask) | (((l + 16 * i) >> 2) << 16);
+        total += __popc(cm);
+        // rare: a sub-list whose 4th entry is within tau is scanned whole.  The loop is wave-uniform (any row of the wave):
+        // each row walks ITS full sub-lists, rows without one idle
+        unsigned f = full;
+        while (__any(f != 0u)) {
+            if (f) {
+                const int src = __ffs(static_cast<int>(f)) - 1;
+                f &= f - 1u;
+                const int sub = (src + 16 * i) >> 2, split = sub >> 1, hh = sub & 1;
+                for (int idx = l; idx < tiles_per_split * 64; idx += 16) {
+                    const int tile = idx >> 6, rem = idx & 63;
+                    const int row = (split * tiles_per_split + tile) * H_TT + 32 * (rem >> 4) + 8 * ((rem >> 2) & 3) + 4 * hh + (rem & 3);
+                    if (row < nt) best.insert(K::make(hamming256(q0, q1, T, row), row));
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // candidate groups: 8 rows each, one row per lane, two groups per pass and query
+    for (int base = 0; __any(base < 8 * total); base += 16) {
+        const int t = base + l;
+        if (t < 8 * total) {
+            const int ent = clist[wave][qi][t >> 3];
+            const int gid2 = ent & 0xFFFF, gid = gid2 >> 1, hh = gid2 & 1, split = ent >> 17;
+            const int s8 = t & 7;
+            const int row = (split * tiles_per_split + (gid >> 3)) * H_TT + 32 * ((gid >> 1) & 3) + 16 * (gid & 1) + 4 * hh +
+                            8 * (s8 >> 2) + (s8 & 3);
+            if (row < nt) best.insert(K::make(hamming256(q0, q1, T, row), row));
+        }
+    }
+    for (int c = 0; c < k; ++c) {
+        const typename K::type m = row16_min(best.a);
+        if (best.a == m && m != K::NONE) { best.a = best.b; best.b = K::NONE; }      // keys are unique rows
+        if (l == 0 && live) {
+            pm_match mm;
+            mm.queryIdx = q;
+            mm.imgIdx = 0;
+            if (m == K::NONE) { mm.trainIdx = -1; mm.distance = HM_INF; }
+            else { mm.trainIdx = K::row(m); mm.distance = static_cast<float>(K::dist(m)); }
+            out[static_cast<size_t>(q) * k + c] = mm;
+        }
+    }
+}
+
 // 256-bit descriptors, k <= 2
 int run_mfma(pm_ctx* ctx, const uint32_t* dq, int nq, const uint32_t* dt, int nt, int k, pm_match* dout, bool wide_keys,
              bool* done)
@@ -412,9 +535,20 @@ int run_mfma(pm_ctx* ctx, const uint32_t* dq, int nq, const uint32_t* dt, int nt
 #define PM_HREFINE(NE_, K_)                                                                                      \
     hipLaunchKernelGGL((knn_hamming_refine<NE_, K_>), dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, dq, dt, nq, nt, k, \
                        cval, slots, tiles_per_split, shift, dout)
+#define PM_HREFINE4(NE_, K_)                                                                                      \
+    hipLaunchKernelGGL((knn_hamming_refine4<NE_, K_>), dim3((nq + 15) / 16), dim3(256), 0, ctx->stream, dq, dt, nq, nt, k, \
+                       cval, slots, tiles_per_split, shift, dout)
+    // PM_OPT_HAMMING_REFINE = 2: four queries per wave (round 3, slots <= 64).  Measured at config C4: 127 us against 31 us
+    // for one wave per query — Hamming distances tie all the time, a sub-list whose 4th entry is within tau is the NORMAL
+    // case for a good share of the queries, and scanning it costs 16 lanes four times the iterations it costs 64 (and the
+    // other three queries of the wave wait).  Not the default.
+    const bool rows16 = slots <= 64 && ctx->opts[PM_OPT_HAMMING_REFINE] == 2;
 #define PM_HREFINE_K(K_)                    \
     do {                                    \
-        if (slots <= 64) PM_HREFINE(1, K_); \
+        if (rows16 && slots <= 16) PM_HREFINE4(1, K_); \
+        else if (rows16 && slots <= 32) PM_HREFINE4(2, K_); \
+        else if (rows16) PM_HREFINE4(4, K_); \
+        else if (slots <= 64) PM_HREFINE(1, K_); \
         else if (slots <= 128) PM_HREFINE(2, K_); \
         else if (slots <= 256) PM_HREFINE(4, K_); \
         else PM_HREFINE(HR_MAXE, K_);       \
@@ -422,6 +556,7 @@ int run_mfma(pm_ctx* ctx, const uint32_t* dq, int nq, const uint32_t* dt, int nt
         if (nt < (1 << 23) && !wide_keys) PM_HREFINE_K(Key32);
         else PM_HREFINE_K(Key64);
 #undef PM_HREFINE_K
+#undef PM_HREFINE4
 #undef PM_HREFINE
         PM_HIP_CHECK(hipGetLastError());
     }

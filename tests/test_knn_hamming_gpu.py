@@ -79,6 +79,30 @@ def test_hamming_i8_route_matches_valu_route_and_oracle(ctx, oracle, nq, nt, k):
     assert_matches_equal(got, oracle.bf_knn_hamming(q, t, k), "i8 vs oracle")
 
 
+@pytest.mark.parametrize("nq,nt,k", [(700, 1000, 2), (257, 129, 1), (5, 128, 2), (1030, 4100, 2), (64, 2, 2), (33, 9000, 2), (4099, 600, 1),
+                                     (2048, 2048, 2)])
+def test_hamming_refinement_forms_same_result(ctx, oracle, nq, nt, k):
+    """PM_OPT_HAMMING_REFINE: one wave per query (round 1) and four queries per wave on 16-lane rows (round 3), on planted
+    data and on tie-heavy alphabets (every group ties, sub-lists overflow): the same records, = the oracle's."""
+    rng = np.random.default_rng(nq + nt)
+    cases = [synth.orb_like(nq, nt, 32, seed=11 * nq + nt)[:2]]
+    base = rng.integers(0, 256, (4, 32), dtype=np.uint8)
+    tq, tt = base[rng.integers(0, 4, nq)].copy(), base[rng.integers(0, 4, nt)].copy()
+    tt[::5, 0] ^= 1
+    cases.append((tq, tt))
+    for ci, (q, t) in enumerate(cases):
+        want = oracle.bf_knn_hamming(q, t, k, nthreads=8)
+        try:
+            for form in (1, 2, 0):
+                ctx.set_option(pm.api.PM_OPT_HAMMING_REFINE, form)
+                for route in (0, 2):                         # 32-bit / 64-bit keys
+                    ctx.set_option(pm.api.PM_OPT_HAMMING_ROUTE, route)
+                    assert_matches_equal(ctx.bf_knn_hamming(q, t, k), want, "case %d refinement form %d route %d" % (ci, form, route))
+        finally:
+            ctx.set_option(pm.api.PM_OPT_HAMMING_REFINE, 0)
+            ctx.set_option(pm.api.PM_OPT_HAMMING_ROUTE, 0)
+
+
 def test_hamming_i8_route_is_the_one_timed(ctx):
     q, t, _ = synth.orb_like(512, 512, 32, seed=5)
     ctx.timing_enable(True)

@@ -105,13 +105,16 @@ def hamming_case(i):
     else:
         q, t, _ = synth.orb_like(nq, nt, nbytes, seed=int(rng.integers(1 << 30)), flip=float(rng.uniform(0.0, 0.3)))
     route = int(rng.integers(0, 3))
+    hform = int(rng.integers(0, 3))                          # refinement: automatic / one wave per query / four queries per wave
     try:
         ctx.set_option(A.PM_OPT_HAMMING_ROUTE, route)
-        trace("hamming", i, nq, nt, nbytes, "k", k, "route", route)
+        ctx.set_option(A.PM_OPT_HAMMING_REFINE, hform)
+        trace("hamming", i, nq, nt, nbytes, "k", k, "route", route, "refine", hform)
         assert_matches_equal(ctx.bf_knn_hamming(q, t, k), O.bf_knn_hamming(q, t, k, nthreads=NT),
                              "Hamming case %d: %dx%d bytes=%d k=%d route=%d" % (i, nq, nt, nbytes, k, route))
     finally:
         ctx.set_option(A.PM_OPT_HAMMING_ROUTE, 0)
+        ctx.set_option(A.PM_OPT_HAMMING_REFINE, 0)
 
 
 def same_ransac(got, want, what):
