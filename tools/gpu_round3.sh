@@ -24,6 +24,7 @@ step bench_c4 300 bash -c "python bench.py --workload c4 > $O/bench_c4.json 2> $
 step bench_c5 300 bash -c "python bench.py --workload c5 --steps 5 --warmup 5 > $O/bench_c5.json 2> $O/bench_c5.err"
 step bench_c5s 300 bash -c "python bench.py --workload c5 --c5-layout separate --steps 5 --warmup 5 > $O/bench_c5_separate_buffers.json 2> $O/bench_c5_separate_buffers.err"
 step bench_c5u 300 bash -c "python bench.py --workload c5 --c5-desc u8 --steps 5 --warmup 5 > $O/bench_c5_u8.json 2> $O/bench_c5_u8.err"
+step bench_c5u3 300 bash -c "python bench.py --workload c5 --c5-desc u8 --lanes 3 --c5-host-threads 1 --ransac-wg-ids 0 --steps 5 --warmup 5 > $O/bench_c5_u8_3lanes_1thread_spread_ids.json 2> $O/bench_c5_u8_3lanes.err"
 step bench_c3p 300 bash -c "python bench.py --pipeline 1 --no-cpu-baseline --no-large > $O/bench_c3_pipelined.json 2> $O/bench_c3_pipelined.err"
 step bench_c3a 300 bash -c "python bench.py --hint auto --no-cpu-baseline --no-large > $O/bench_c3_auto_route.json 2> $O/bench_c3_auto_route.err"
 step bench_surf 300 bash -c "python bench.py --kind surf --no-cpu-baseline > $O/bench_c3_surf.json 2> $O/bench_c3_surf.err"
@@ -35,6 +36,9 @@ step fallback 300 bash -c "python tools/fallback_perf.py > $O/fallback_perf.json
 step mgpu 300 bash -c "python tools/mgpu_stream_bench.py > $O/mgpu_stream.txt 2>&1"
 step flann 300 bash -c "python tools/prof_flann.py > $O/flann.txt 2>&1"
 step wide 300 bash -c "python tools/sweep_ratio.py 8192 8192 > $O/sweep_ratio_8192.txt 2>&1"
+step forms32k 300 bash -c "python tools/sweep_u8.py 32768 32768 '' '12=2' '12=3' '12=4' '12=5' '12=6' > $O/sweep_u8_forms_32k.txt 2>&1"
+step forms16k 300 bash -c "python tools/sweep_u8.py 16384 16384 '' '12=5' '12=6' > $O/sweep_u8_forms_16k.txt 2>&1"
+step knnstamps 300 bash -c "for o in '' '12=6'; do echo == options \$o; PM_LIB_PATH=points_matching_amd/build/abl/libpm_knnstamps.so python tools/prof_knn_stamps.py 32768 32768 \$o; done > $O/knn_stamps_32k.txt 2>&1"
 step stamps 200 bash -c "for f in 1 2; do echo == PM_OPT_RANSAC_FORM \$f; PM_RANSAC_FORM=\$f PM_LIB_PATH=points_matching_amd/build/abl/libpm_rfstamps.so python tools/prof_ransac_stamps.py; done > $O/ransac_stamps.txt 2>&1"
 step h2d 200 bash -c "python tools/h2d_ceiling.py > $O/h2d_ceiling.txt 2>&1"
 cd /tmp && export TMPDIR=/tmp
