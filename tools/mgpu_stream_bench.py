@@ -29,8 +29,10 @@ for _ in range(3):
 t_block = (time.perf_counter() - t0) / 3
 print("n_dev %d  %d x %d per device, %d hypotheses: blocking pm_mgpu_match_ransac from host memory (pinned staging, train set "
       "uploaded per call) %.3f ms per pair; matches %d inliers %d" % (n_dev, nq, nt, H, t_block * 1e3, base[1].size, base[4]))
-print("all-gather latency by itself: 80 B %.2f us, %d B %.2f us per collective" % (
-    mg.allgather_latency(80), 16 + nq * 32, mg.allgather_latency(16 + nq * 32)))
+print("all-gather latency by itself: 80 B %.2f us, %d B %.2f us per collective%s" % (
+    mg.allgather_latency(80), 16 + nq * 32, mg.allgather_latency(16 + nq * 32),
+    " (ONE device: RCCL's in-place all-gather of a single rank launches nothing, this is the enqueue cost; bench.py "
+    "--exercise-exchange times a torch.distributed collective at world 1: ~10-12 us)" if n_dev == 1 else ""))
 mg.set_train(w["t"], w["kp2"])
 dq, dk, rows = [], [], []
 for g in range(n_dev):
