@@ -266,6 +266,40 @@ __device__ __forceinline__ int hamming256(const uint4 q0, const uint4 q1, const 
     return d;
 }
 
+// All rows of one sub-list's lane stream (split, lane half hh): LANES lanes, U rows per lane and pass with the 2 x U loads
+// of a pass issued together (clamped addresses, no condition in front of a load).  Round 3: the first form of this scan
+// took one row per lane and pass, i.e. tiles_per_split serial memory round trips of ~1k cycles each — at config C4 (64
+// tiles per split) ~25 us for the handful of queries per launch that need it, which was most of the kernel's 31 us: a
+// kernel lasts as long as its slowest wave.
+template <int U, int LANES, typename K>
+__device__ __forceinline__ void scan_sublist(Best2<typename K::type>& best, const uint4 q0, const uint4 q1,
+                                             const uint32_t* __restrict__ T, int nt, int split, int hh, int tiles_per_split, int l)
+{
+    const int n = tiles_per_split * 64;
+    for (int base = 0; base < n; base += LANES * U) {
+        int row[U];
+        bool ok[U];
+        uint4 t0[U], t1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * LANES + l;
+            const int tile = idx >> 6, rem = idx & 63;
+            row[u] = (split * tiles_per_split + tile) * H_TT + 32 * (rem >> 4) + 8 * ((rem >> 2) & 3) + 4 * hh + (rem & 3);
+            ok[u] = idx < n && row[u] < nt;
+            const uint4* tr = reinterpret_cast<const uint4*>(T + static_cast<size_t>(ok[u] ? row[u] : 0) * 8);
+            t0[u] = tr[0];
+            t1[u] = tr[1];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int d = __builtin_popcount(q0.x ^ t0[u].x) + __builtin_popcount(q0.y ^ t0[u].y) + __builtin_popcount(q0.z ^ t0[u].z) +
+                          __builtin_popcount(q0.w ^ t0[u].w) + __builtin_popcount(q1.x ^ t1[u].x) + __builtin_popcount(q1.y ^ t1[u].y) +
+                          __builtin_popcount(q1.z ^ t1[u].z) + __builtin_popcount(q1.w ^ t1[u].w);
+            if (ok[u]) best.insert(K::make(d, row[u]));
+        }
+    }
+}
+
 // One wave per query.  cand: [nq][slots] ints, sub-list s = entries 4s..4s+3 in descending order,
 // s = split*2 + lane half; entry = (dot << shift) | id, id = (tile_in_split*8 + block*2 + group) * 2 + lane half;
 // group (block, g, half hh) = rows 32*block + 16*g + 4*hh + {0,1,2,3, 8,9,10,11} of the tile.
@@ -334,12 +368,7 @@ __global__ __launch_bounds__(256) void knn_hamming_refine(const uint32_t* __rest
             const int src = __ffsll(static_cast<long long>(f)) - 1;
             f &= f - 1ull;
             const int sub = (src + 64 * i) >> 2, split = sub >> 1, hh = sub & 1;      // the rows of that lane half
-            for (int idx = lane; idx < tiles_per_split * 64; idx += 64) {
-                const int tile = idx >> 6, rem = idx & 63;
-                const int row = (split * tiles_per_split + tile) * H_TT + 32 * (rem >> 4) + 8 * ((rem >> 2) & 3) + 4 * hh +
-                                (rem & 3);
-                if (row < nt) best.insert(K::make(hamming256(q0, q1, T, row), row));
-            }
+            scan_sublist<4, 64, K>(best, q0, q1, T, nt, split, hh, tiles_per_split, lane);
         }
     }
     // the list entries were written by other lanes of this wave: LDS stores before the loads, explicitly
@@ -458,11 +487,7 @@ __global__ __launch_bounds__(256) void knn_hamming_refine4(const uint32_t* __res
                 const int src = __ffs(static_cast<int>(f)) - 1;
                 f &= f - 1u;
                 const int sub = (src + 16 * i) >> 2, split = sub >> 1, hh = sub & 1;
-                for (int idx = l; idx < tiles_per_split * 64; idx += 16) {
-                    const int tile = idx >> 6, rem = idx & 63;
-                    const int row = (split * tiles_per_split + tile) * H_TT + 32 * (rem >> 4) + 8 * ((rem >> 2) & 3) + 4 * hh + (rem & 3);
-                    if (row < nt) best.insert(K::make(hamming256(q0, q1, T, row), row));
-                }
+                scan_sublist<4, 16, K>(best, q0, q1, T, nt, split, hh, tiles_per_split, l);
             }
         }
     }
@@ -538,10 +563,10 @@ int run_mfma(pm_ctx* ctx, const uint32_t* dq, int nq, const uint32_t* dt, int nt
 #define PM_HREFINE4(NE_, K_)                                                                                      \
     hipLaunchKernelGGL((knn_hamming_refine4<NE_, K_>), dim3((nq + 15) / 16), dim3(256), 0, ctx->stream, dq, dt, nq, nt, k, \
                        cval, slots, tiles_per_split, shift, dout)
-    // PM_OPT_HAMMING_REFINE = 2: four queries per wave (round 3, slots <= 64).  Measured at config C4: 127 us against 31 us
-    // for one wave per query — Hamming distances tie all the time, a sub-list whose 4th entry is within tau is the NORMAL
-    // case for a good share of the queries, and scanning it costs 16 lanes four times the iterations it costs 64 (and the
-    // other three queries of the wave wait).  Not the default.
+    // PM_OPT_HAMMING_REFINE = 2: four queries per wave (round 3, slots <= 64).  Measured at config C4: 94-98 us against
+    // 27 us for one wave per query, although without the whole-sub-list scans it takes 9.8 us: a launch lasts as long as
+    // its slowest wave, a handful of the 32 768 queries need a scan of 4096 rows, and that scan is 64 dependent passes for
+    // 16 lanes (16 for 64 lanes).  Faster everywhere else (8192^2: 7.9 vs 8.8 us), but not the default.
     const bool rows16 = slots <= 64 && ctx->opts[PM_OPT_HAMMING_REFINE] == 2;
 #define PM_HREFINE_K(K_)                    \
     do {                                    \
