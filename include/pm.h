@@ -123,9 +123,9 @@ enum {
                                    CUs: lowest latency for one run; a pm_batch lane defaults to 32 instead), 1 .. 128 = that
                                    many: fewer, fuller workgroups, so the runs of several streams share the GPU — the fp64
                                    solve costs a wave the same ~21k cycles whether 8 or 64 of its lanes are in use       */
-    PM_OPT_HAMMING_REFINE = 19, /* Hamming matrix-core route, refinement: 1 = one wave per query (default), 2 = four queries per
-                                   wave, one 16-lane row each (<= 64 candidate entries per query; 3.5x slower at config C4:
-                                   the rare whole-sub-list scan of 4096 rows is four times as many passes for 16 lanes) */
+    PM_OPT_HAMMING_REFINE = 19, /* Hamming matrix-core route, refinement: 1 = one wave per query (round 1), 2 = four queries per
+                                   wave, one 16-lane row each (default where a query has <= 64 candidate entries); in both
+                                   the rare whole-sub-list scans are done by the whole workgroup                       */
     PM_OPT_COUNT_         = 20
 };
 int  pm_ctx_set_option(pm_ctx* ctx, int option, int value);

@@ -300,6 +300,46 @@ __device__ __forceinline__ void scan_sublist(Best2<typename K::type>& best, cons
     }
 }
 
+// The rare whole-sub-list scans of a workgroup's queries, done by ALL of its 256 threads (round 3).  A launch lasts as
+// long as its slowest wave: scanning a 4096-row lane stream with the 64 (or 16) lanes that own the query was 16 (64)
+// dependent passes — most of the kernel's time at config C4 although < 0.3 % of the queries need it.  Phase A of the
+// kernels only RECORDS the sub-lists (HmScan in LDS); here every thread scans its share for one owner at a time and leaves
+// its two best keys in LDS, from where the owner's lanes merge them.  NOWN owners per workgroup, LPO lanes per owner.
+template <int NOWN, int MAXSUB, typename K>
+struct HmScan {
+    uint4 qw[NOWN][2];                                       // the owner's descriptor (first member: 16-byte aligned)
+    typename K::type keys[256][2];
+    int nsub[NOWN];
+    int sub[NOWN][MAXSUB];
+};
+template <int NOWN, int MAXSUB, int LPO, typename K>
+__device__ __forceinline__ void wg_scan_phase(HmScan<NOWN, MAXSUB, K>& hs, Best2<typename K::type>& best, int owner, int l,
+                                              const uint32_t* __restrict__ T, int nt, int tiles_per_split)
+{
+    __syncthreads();                                         // every owner's record is complete
+    for (int w = 0; w < NOWN; ++w) {
+        const int n = hs.nsub[w];                            // workgroup-uniform
+        if (n == 0) continue;
+        const uint4 q0 = hs.qw[w][0], q1 = hs.qw[w][1];
+        Best2<typename K::type> tb{K::NONE, K::NONE};
+        for (int j = 0; j < n; ++j) {
+            const int sb = hs.sub[w][j];
+            scan_sublist<4, 256, K>(tb, q0, q1, T, nt, sb >> 1, sb & 1, tiles_per_split, static_cast<int>(threadIdx.x));
+        }
+        hs.keys[threadIdx.x][0] = tb.a;
+        hs.keys[threadIdx.x][1] = tb.b;
+        __syncthreads();
+        if (owner == w) {
+#pragma unroll
+            for (int u = 0; u < 256 / LPO; ++u) {
+                best.insert(hs.keys[l + LPO * u][0]);
+                best.insert(hs.keys[l + LPO * u][1]);
+            }
+        }
+        __syncthreads();                                     // keys[] is free again
+    }
+}
+
 // One wave per query.  cand: [nq][slots] ints, sub-list s = entries 4s..4s+3 in descending order,
 // s = split*2 + lane half; entry = (dot << shift) | id, id = (tile_in_split*8 + block*2 + group) * 2 + lane half;
 // group (block, g, half hh) = rows 32*block + 16*g + 4*hh + {0,1,2,3, 8,9,10,11} of the tile.
@@ -313,10 +353,12 @@ __global__ __launch_bounds__(256) void knn_hamming_refine(const uint32_t* __rest
                                                           pm_match* __restrict__ out)
 {
     __shared__ int clist[4][64 * NE];
+    __shared__ __attribute__((aligned(16))) HmScan<4, 16 * NE, K> hs;      // (a query has slots / 4 <= 16 * NE sub-lists)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + wave;
-    if (q >= nq) return;                                     // wave-uniform; no block barriers below
-    const uint4* qr = reinterpret_cast<const uint4*>(Q + static_cast<size_t>(q) * 8);
+    const bool live = q < nq;                                // (dead waves shadow the last query: the workgroup has barriers)
+    const int qc = live ? q : nq - 1;
+    const uint4* qr = reinterpret_cast<const uint4*>(Q + static_cast<size_t>(qc) * 8);
     const uint4 q0 = qr[0], q1 = qr[1];
     const int gmask = (1 << shift) - 1;
 
@@ -325,7 +367,7 @@ __global__ __launch_bounds__(256) void knn_hamming_refine(const uint32_t* __rest
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         const int e = lane + 64 * i;
-        v[i] = e < slots ? cand[static_cast<size_t>(q) * slots + e] : I8_EMPTY;
+        v[i] = e < slots ? cand[static_cast<size_t>(qc) * slots + e] : I8_EMPTY;
         dc[i] = v[i] == I8_EMPTY ? 0x7FFFFFF0 : ((I8_BITS - (v[i] >> shift)) >> 1);      // coarse (= exact) distance
         const int gid2 = v[i] & gmask, gid = gid2 >> 1, split = e >> 3;
         const int last = (split * tiles_per_split + (gid >> 3)) * H_TT + 32 * ((gid >> 1) & 3) + 16 * (gid & 1) +
@@ -352,7 +394,7 @@ __global__ __launch_bounds__(256) void knn_hamming_refine(const uint32_t* __rest
     if (tau == 0x7FFF) tau = 0x7FFFFFFF;                     // fewer than k whole groups: everything is a candidate
     // sub-lists whose 4th entry is within tau may have dropped a row within tau: scan them whole
     Best2<typename K::type> best{K::NONE, K::NONE};
-    int total = 0;
+    int total = 0, nfull = 0;
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         if (64 * i >= slots) break;                          // wave-uniform
@@ -363,14 +405,15 @@ __global__ __launch_bounds__(256) void knn_hamming_refine(const uint32_t* __rest
         if (within && !my_full)
             clist[wave][total + __popcll(cm & ((1ull << lane) - 1ull))] = (v[i] & gmask) | (((lane + 64 * i) >> 2) << 16);
         total += __popcll(cm);
-        unsigned long long f = full;
-        while (f) {                                          // rare
-            const int src = __ffsll(static_cast<long long>(f)) - 1;
-            f &= f - 1ull;
-            const int sub = (src + 64 * i) >> 2, split = sub >> 1, hh = sub & 1;      // the rows of that lane half
-            scan_sublist<4, 64, K>(best, q0, q1, T, nt, split, hh, tiles_per_split, lane);
+        // rare: a sub-list whose 4th entry is within tau is scanned whole — by the workgroup, below; recorded here
+        if (full) {
+            const unsigned long long fb = (1ull << lane) & full;
+            if (fb && live) hs.sub[wave][nfull + __popcll(full & ((1ull << lane) - 1ull))] = (lane + 64 * i) >> 2;
+            nfull += __popcll(full);
         }
     }
+    if (lane == 0) hs.nsub[wave] = live ? nfull : 0;
+    if (lane == 0) { hs.qw[wave][0] = q0; hs.qw[wave][1] = q1; }
     // the list entries were written by other lanes of this wave: LDS stores before the loads, explicitly
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -386,10 +429,11 @@ __global__ __launch_bounds__(256) void knn_hamming_refine(const uint32_t* __rest
             if (row < nt) best.insert(K::make(hamming256(q0, q1, T, row), row));
         }
     }
+    wg_scan_phase<4, 16 * NE, 64, K>(hs, best, wave, lane, T, nt, tiles_per_split);
     for (int c = 0; c < k; ++c) {
         const typename K::type m = K::wave_min(best.a);
         if (best.a == m && m != K::NONE) { best.a = best.b; best.b = K::NONE; }      // keys are unique rows
-        if (lane == 0) {
+        if (lane == 0 && live) {
             pm_match mm;
             mm.queryIdx = q;
             mm.imgIdx = 0;
@@ -400,8 +444,7 @@ __global__ __launch_bounds__(256) void knn_hamming_refine(const uint32_t* __rest
     }
 }
 
-// Round 3 (built, measured SLOWER at config C4, kept behind PM_OPT_HAMMING_REFINE = 2: see run_mfma):
-// FOUR queries per wave, one 16-lane row each (the form of knn_l2_refine8): at config C4 a query has 32 candidate
+// Round 3: FOUR queries per wave, one 16-lane row each (the form of knn_l2_refine8): at config C4 a query has 32 candidate
 // entries, half a wave; the k-th-smallest search and the final top-k become 4-step DPP reductions inside a row (row_ror,
 // no v_readlane), the instruction stream of a wave serves four queries.  Same entry layout, same tau / full-sub-list /
 // candidate rules and therefore the same rows evaluated as knn_hamming_refine above; for slots <= 64 (NE = 1, 2 or 4
@@ -431,8 +474,10 @@ __global__ __launch_bounds__(256) void knn_hamming_refine4(const uint32_t* __res
                                                            pm_match* __restrict__ out)
 {
     __shared__ int clist[4][4][16 * NE];
+    __shared__ __attribute__((aligned(16))) HmScan<16, 4 * NE, K> hs;      // (a query has slots / 4 <= 4 * NE sub-lists)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int qi = lane >> 4, l = lane & 15;
+    const int own = wave * 4 + qi;                           // this row's query inside the workgroup
     const int q = blockIdx.x * 16 + wave * 4 + qi;
     const bool live = q < nq;
     const int qc = live ? q : nq - 1;                        // rows past the last query shadow it (DPP rows stay whole)
@@ -469,7 +514,7 @@ __global__ __launch_bounds__(256) void knn_hamming_refine4(const uint32_t* __res
     }
     if (tau == 0x7FFF) tau = 0x7FFFFFFF;
     Best2<typename K::type> best{K::NONE, K::NONE};
-    int total = 0;
+    int total = 0, nfull = 0;
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         if (16 * i >= slots) break;                          // wave-uniform
@@ -479,18 +524,12 @@ __global__ __launch_bounds__(256) void knn_hamming_refine4(const uint32_t* __res
         const unsigned cm = row_bits(within && !my_full);
         if (within && !my_full) clist[wave][qi][total + __popc(cm & ((1u << l) - 1u))] = (v[i] & gmask) | (((l + 16 * i) >> 2) << 16);
         total += __popc(cm);
-        // rare: a sub-list whose 4th entry is within tau is scanned whole.  The loop is wave-uniform (any row of the wave):
-        // each row walks ITS full sub-lists, rows without one idle
-        unsigned f = full;
-        while (__any(f != 0u)) {
-            if (f) {
-                const int src = __ffs(static_cast<int>(f)) - 1;
-                f &= f - 1u;
-                const int sub = (src + 16 * i) >> 2, split = sub >> 1, hh = sub & 1;
-                scan_sublist<4, 16, K>(best, q0, q1, T, nt, split, hh, tiles_per_split, l);
-            }
-        }
+        // rare: a sub-list whose 4th entry is within tau is scanned whole — by the workgroup, below; recorded here
+        if ((full >> l) & 1u) { if (live) hs.sub[own][nfull + __popc(full & ((1u << l) - 1u))] = (l + 16 * i) >> 2; }
+        nfull += __popc(full);
     }
+    if (l == 0) hs.nsub[own] = live ? nfull : 0;
+    if (l == 0) { hs.qw[own][0] = q0; hs.qw[own][1] = q1; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // candidate groups: 8 rows each, one row per lane, two groups per pass and query
@@ -505,6 +544,7 @@ __global__ __launch_bounds__(256) void knn_hamming_refine4(const uint32_t* __res
             if (row < nt) best.insert(K::make(hamming256(q0, q1, T, row), row));
         }
     }
+    wg_scan_phase<16, 4 * NE, 16, K>(hs, best, own, l, T, nt, tiles_per_split);
     for (int c = 0; c < k; ++c) {
         const typename K::type m = row16_min(best.a);
         if (best.a == m && m != K::NONE) { best.a = best.b; best.b = K::NONE; }      // keys are unique rows
@@ -563,11 +603,11 @@ int run_mfma(pm_ctx* ctx, const uint32_t* dq, int nq, const uint32_t* dt, int nt
 #define PM_HREFINE4(NE_, K_)                                                                                      \
     hipLaunchKernelGGL((knn_hamming_refine4<NE_, K_>), dim3((nq + 15) / 16), dim3(256), 0, ctx->stream, dq, dt, nq, nt, k, \
                        cval, slots, tiles_per_split, shift, dout)
-    // PM_OPT_HAMMING_REFINE = 2: four queries per wave (round 3, slots <= 64).  Measured at config C4: 94-98 us against
-    // 27 us for one wave per query, although without the whole-sub-list scans it takes 9.8 us: a launch lasts as long as
-    // its slowest wave, a handful of the 32 768 queries need a scan of 4096 rows, and that scan is 64 dependent passes for
-    // 16 lanes (16 for 64 lanes).  Faster everywhere else (8192^2: 7.9 vs 8.8 us), but not the default.
-    const bool rows16 = slots <= 64 && ctx->opts[PM_OPT_HAMMING_REFINE] == 2;
+    // Four queries per wave (round 3) where a query has <= 64 candidate entries; PM_OPT_HAMMING_REFINE = 1 keeps one wave
+    // per query.  Config C4, refinement kernel: 31 us (round 2) -> 27 (batched scan loads) -> 22.3 (whole-sub-list scans
+    // by the workgroup, one wave per query) / 20.8 us (four queries per wave); before the scans went to the workgroup the
+    // four-queries form took 94-128 us there — a launch lasts as long as its slowest wave.
+    const bool rows16 = slots <= 64 && ctx->opts[PM_OPT_HAMMING_REFINE] != 1;
 #define PM_HREFINE_K(K_)                    \
     do {                                    \
         if (rows16 && slots <= 16) PM_HREFINE4(1, K_); \
