@@ -1049,6 +1049,54 @@ __device__ __forceinline__ unsigned long long row_min_u64(unsigned long long v)
     return (static_cast<unsigned long long>(mh) << 32) | ml;
 }
 
+// Exact re-scans of knn_l2_refine8 (round 3).  A list whose 4th entry is inside the window may have dropped candidates
+// (SPEC S1b), so the rows of that split are evaluated exactly; runs of identical train rows — repeated texture — make that
+// a common case (12 identical rows fill a list with four groups at the same distance).  The first form of this kernel let
+// the query's 16 lanes walk ALL train rows: 512 dependent passes at 8192 rows, and because a launch lasts as long as its
+// slowest wave the matcher call went from 23 to 225 us with 52 such queries among 8192 (1 ms at 32k x 32k).  Now only the
+// spilled SPLITS are evaluated, by all 64 lanes of the wave for one of its four queries at a time (a variant that handed
+// them to the whole workgroup cut the tail further but cost every launch a barrier: +1 us at config C3).
+template <int KM, int U, int LANES>
+__device__ __forceinline__ void r8_scan_rows(BestN<KM>& tb, const uint4 (&qv)[U8_ROW16], int qn, const uint4* __restrict__ T8,
+                                             const float* __restrict__ tnorm, int t_row16, int row_begin, int row_end, int me)
+{
+    for (int base = row_begin; base < row_end; base += LANES * U) {
+        int d2[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int row = base + u * LANES + me;
+            ok[u] = row < row_end;
+            // the row in two halves of four 16-byte loads: the register peak of this rare path must not cost the common
+            // path a wave per SIMD (whole rows in flight: 106 VGPRs, 4 waves; measured +0.25 us per launch at config C3)
+            const uint4* tp = T8 + static_cast<size_t>(ok[u] ? row : row_begin) * t_row16;
+            int acc = 0;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                uint4 tv[U8_ROW16 / 2];
+#pragma unroll
+                for (int i = 0; i < U8_ROW16 / 2; ++i) tv[i] = tp[hf * (U8_ROW16 / 2) + i];
+#pragma unroll
+                for (int i = 0; i < U8_ROW16 / 2; ++i) {
+                    const uint4 a = qv[hf * (U8_ROW16 / 2) + i];
+                    acc = __builtin_amdgcn_sdot4(static_cast<int>(a.x), static_cast<int>(tv[i].x), acc, false);
+                    acc = __builtin_amdgcn_sdot4(static_cast<int>(a.y), static_cast<int>(tv[i].y), acc, false);
+                    acc = __builtin_amdgcn_sdot4(static_cast<int>(a.z), static_cast<int>(tv[i].z), acc, false);
+                    acc = __builtin_amdgcn_sdot4(static_cast<int>(a.w), static_cast<int>(tv[i].w), acc, false);
+                }
+                asm volatile("" : "+v"(acc));                 // (keeps the second half's loads behind the first half's use)
+            }
+            d2[u] = qn + static_cast<int>(tnorm[ok[u] ? row : row_begin]) - 2 * acc;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int row = base + u * LANES + me;
+            const float d = __builtin_sqrtf(static_cast<float>(d2[u]));
+            if (ok[u]) tb.insert(knn_key(d, row), d);
+        }
+    }
+}
+
 // FUSE (k == 2): the ratio test, the stable compaction and the keypoint gather (main.cpp:49-69 in its ratio form, :77-78,
 // :89-91) ride this launch.  A workgroup holds 16 whole queries, so nothing is handed between workgroups but ONE
 // epoch-tagged survivor count each (decoupled look-back over the earlier workgroups, as in filter_ratio_gather); `out`
@@ -1104,25 +1152,34 @@ __global__ __launch_bounds__(256) void knn_l2_refine8(
         const unsigned owners = static_cast<unsigned>(__ballot(mn.m[0] == tau) >> (16 * qi)) & 0xFFFFu;
         if (l == __ffs(static_cast<int>(owners)) - 1) mn.pop(IMAX);
     }
-    bool full = wrong_hint || tau == IMAX;                   // fewer than k ranked groups (nt < k, ...): scan everything
+    const bool full = wrong_hint || tau == IMAX;             // fewer than k ranked groups (nt < k, ...): scan everything
     const int thr = tau == IMAX ? 0 : tau + 1;
 
+    // a list whose 4th entry is inside the window may have dropped candidates: the rows of that SPLIT are evaluated exactly
+    // (by the workgroup, below); its ranked groups are then not expanded a second time
+    unsigned long long spill = 0ull;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        if (16 * i >= slots) break;                          // wave-uniform
+        const int s = l + 16 * i;
+        unsigned sp = static_cast<unsigned>(__ballot(s < slots && !full && (s & (KNN_C - 1)) == KNN_C - 1 && val[i] <= thr) >> (16 * qi)) & 0xFFFFu;
+        while (sp) {                                         // (at most four lists per 16 slots)
+            const int bit = __ffs(static_cast<int>(sp)) - 1;
+            sp &= sp - 1u;
+            spill |= 1ull << ((bit + 16 * i) >> 2);
+        }
+    }
     int total = 0;
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         if (16 * i >= slots) break;                          // wave-uniform
         const int s = l + 16 * i;
-        const bool in = s < slots && !full;
-        const int v = val[i];
-        // a list whose 4th entry is inside the window may have dropped candidates: that query scans everything
-        const unsigned spilled = static_cast<unsigned>(__ballot(in && (s & (KNN_C - 1)) == KNN_C - 1 && v <= thr) >> (16 * qi)) & 0xFFFFu;
-        const bool is_cand = in && v <= thr;
+        const bool is_cand = s < slots && !full && val[i] <= thr && !((spill >> (s >> 2)) & 1ull);
         const unsigned rm = static_cast<unsigned>(__ballot(is_cand) >> (16 * qi)) & 0xFFFFu;
         if (is_cand) clist[wave][qi][total + __popc(rm & ((1u << l) - 1u))] = code[i];
         total += __popc(rm);
-        if (spilled) full = true;
     }
-    if (diag && l == 0 && live && full) { atomicAdd(&diag[0], 1u); if (wrong_hint) diag[1] = 1u; }
+    if (diag && l == 0 && live && (full || spill)) { atomicAdd(&diag[0], 1u); if (wrong_hint) diag[1] = 1u; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -1143,16 +1200,48 @@ __global__ __launch_bounds__(256) void knn_l2_refine8(
             if (row < nt) take(row);
         }
     }
-    if (__any(full)) {                                       // rare: 16 lanes walk all train rows of such a query
-        if (wrong_hint) {                                    // canonical scan of the f32 rows (the hint only costs time)
-            const float* qp = Q + static_cast<size_t>(qc) * dim;
-            for (int j = l; j < nt; j += 16) {
-                const float d = __builtin_sqrtf(l2sqr_canonical<true>(qp, T + static_cast<size_t>(j) * dim, dim));
-                b.insert(knn_key(d, j), d);
+    if (wrong_hint) {                                        // canonical scan of the f32 rows (a wrong hint only costs time)
+        const float* qp = Q + static_cast<size_t>(qc) * dim;
+        for (int j = l; j < nt; j += 16) {
+            const float d = __builtin_sqrtf(l2sqr_canonical<true>(qp, T + static_cast<size_t>(j) * dim, dim));
+            b.insert(knn_key(d, j), d);
+        }
+    }
+    // ---- exact re-scans, by the whole WAVE for one of its four queries at a time (no barrier, no LDS: the common case pays
+    // one ballot).  The owner row's masks reach the other 48 lanes by shuffles, its bytes are read again; every lane keeps the KM best keys
+    // of the rows it evaluated, and KM wave-wide minimum reductions hand the best of them to the owner.
+    {
+        const bool need = live && !wrong_hint && (full || spill != 0ull);
+        unsigned long long needy = __ballot(need && l == 0);             // bit 16*qi: row qi needs a scan
+        while (needy) {
+            const int src = __ffsll(static_cast<long long>(needy)) - 1;      // the owner row's first lane
+            needy &= needy - 1ull;
+            const int oqi = __shfl(qc, src, 64);                            // the owner's query: its bytes again (one address per wave)
+            uint4 oq[U8_ROW16];
+#pragma unroll
+            for (int i = 0; i < U8_ROW16; ++i) oq[i] = Q8[static_cast<size_t>(oqi) * U8_ROW16 + i];
+            const int oqn = __shfl(qn, src, 64);
+            const int oall = __shfl(full ? 1 : 0, src, 64);
+            const unsigned mlo = __shfl(static_cast<unsigned>(spill), src, 64), mhi = __shfl(static_cast<unsigned>(spill >> 32), src, 64);
+            unsigned long long mm = oall ? 0ull : ((static_cast<unsigned long long>(mhi) << 32) | mlo);
+            BestN<KM> tb;
+            tb.init();
+            const int rows_per_split = tiles_per_split * H_TT;
+            if (oall) {
+                r8_scan_rows<KM, 1, 64>(tb, oq, oqn, T8, tnorm, t_row16, 0, nt, lane);
+            } else {
+                while (mm) {
+                    const int sp = __ffsll(static_cast<long long>(mm)) - 1;
+                    mm &= mm - 1ull;
+                    const int r0 = sp * rows_per_split;
+                    r8_scan_rows<KM, 1, 64>(tb, oq, oqn, T8, tnorm, t_row16, r0, r0 + rows_per_split < nt ? r0 + rows_per_split : nt, lane);
+                }
             }
-        } else {
-            for (int j0 = 0; j0 < nt; j0 += 16)
-                if (full && j0 + l < nt) take(j0 + l);
+            for (int j = 0; j < KM; ++j) {                               // the KM best of the wave's keys -> the owner's first lane
+                const uint64_t m = pm::wave_min_u64(tb.k[0]);
+                if (tb.k[0] == m && m != ~0ull) tb.pop();                // (keys are distinct rows)
+                if (lane == src && m != ~0ull) b.insert(m, __uint_as_float(static_cast<unsigned>(m >> 32)));
+            }
         }
     }
     int nn_idx[2] = {-1, -1};                                // the first two neighbours of the row's query (FUSE)
