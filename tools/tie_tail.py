@@ -35,3 +35,22 @@ for name, flags in (("u8 hint", pm.api.PM_KNN_HINT_U8), ("integer hint (f16 pass
         ctx.bf_knn_l2_dev(d_q.data_ptr(), n, d_t.data_ptr(), n, 128, 2, d_out.data_ptr(), flags)
     e1.record(st_); torch.cuda.synchronize()
     print("%d x %d, %d runs of %d identical train rows: %-24s call %.1f us, re-scanned queries %d" % (n, n, runs, ln, name, e0.elapsed_time(e1) * 100, st["rescans"]))
+
+# ---- the same for the Hamming matcher (ORB-256): runs of identical train rows
+qh, th, _ = synth.orb_like(n, n, 32, seed=6)
+for _ in range(runs):
+    a = int(rng.integers(0, n)); b = int(rng.integers(0, n - ln))
+    th[b:b + ln] = th[a]
+    qh[rng.integers(0, n, 3)] = th[a]
+d_qh, d_th = torch.from_numpy(qh).to(dev), torch.from_numpy(th).to(dev)
+for name, form in (("four queries per wave (default)", 0), ("one wave per query", 1)):
+    ctx.set_option(pm.api.PM_OPT_HAMMING_REFINE, form)
+    for _ in range(3):
+        ctx.bf_knn_hamming_dev(d_qh.data_ptr(), n, d_th.data_ptr(), n, 32, 2, d_out.data_ptr())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st_)
+    for _ in range(10):
+        ctx.bf_knn_hamming_dev(d_qh.data_ptr(), n, d_th.data_ptr(), n, 32, 2, d_out.data_ptr())
+    e1.record(st_); torch.cuda.synchronize()
+    print("%d x %d ORB-256, %d runs of %d identical train rows: Hamming matcher, refinement %-32s call %.1f us" % (n, n, runs, ln, name, e0.elapsed_time(e1) * 100))
+ctx.set_option(pm.api.PM_OPT_HAMMING_REFINE, 0)
