@@ -943,7 +943,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void knn_mfma_ring(
     if (tile1 > ntiles) tile1 = ntiles;
     const int ntl = tile1 - tile0;
 
-    // query fragments first: they are the oldest vector-memory operations, so the first counted wait covers them
+    // query fragments: register loads, while every later operation is an LDS-DMA piece.  The two kinds do NOT retire in one
+    // order (knn_u8_rega, form 5: a counted wait over a mix of them returned early), so the FIRST wait of the sweep is a
+    // full drain, vmcnt(0) — it covers the fragments and the prologue's tiles; from then on only pieces are in flight and the
+    // waits are counted.
     frag qf[NQB][R::NCH];
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb)
@@ -987,7 +990,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void knn_mfma_ring(
     pump(0, pro);
     if constexpr (SPLIT) {
         if (ntl > 0) {                                       // arrive for tile 0 (later tiles: one tile ahead, inside the sweep)
-            wait_tiles<BASE>(next - 1, plus);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the full drain: see the query fragments above)
             bump(&arrive[0]);
         }
     }
@@ -1012,7 +1015,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void knn_mfma_ring(
                 }
             } else {
                 // tiles after tix that may stay in flight: everything requested so far beyond tix
-                wait_tiles<BASE>(next - 1 - tix, plus);     // (also covers the query fragments: they are older than tile 0)
+                if (tix == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the full drain (query fragments: see above)
+                else wait_tiles<BASE>(next - 1 - tix, plus);
                 if constexpr (!ABL::no_barrier) __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
             }
@@ -1268,15 +1272,20 @@ __global__ __launch_bounds__(RA_WAVES * 64, 1) void knn_u8_rega(const uint4* __r
     struct Ops { frag a[U8_NCH]; Seed64 s; };
     // PRIV: source offset (bytes inside the block) of this lane's slot of each DMA piece; a lane that lands in a row's pad
     // slot, or behind the 32nd row, re-reads a valid unit (never used)
-    // WSPLIT: the train copy has 144-byte rows (knn_shared.hpp, "wide" rows): the LDS image of a block IS its memory
-    // image, pieces are lane-linear and the block's seeds arrive in the pad slots of its first eight rows
-    constexpr int T_ROW_BYTES = (WSPLIT ? U8_WIDE_ROW16 : U8_ROW16) * 16;
+    // PRIV: the train copy has 144-byte rows (knn_shared.hpp, "wide" rows): the LDS image of a block IS its memory image,
+    // pieces are lane-linear and the block's seeds arrive in the pad slots of its first eight rows — so that EVERY
+    // operation a counted wait covers is an LDS-DMA piece.  (The first version of form 5 loaded the seeds to registers
+    // with global_load_dwordx4 between the pieces and waited vmcnt(18) for "everything but the two youngest blocks": it
+    // returned wrong neighbours for a few queries per launch, differently on every run, and was correct with vmcnt(0) —
+    // LDS-DMA pieces and register loads do not retire in one order, whatever the counter's description says.  Found by
+    // tools/fuzz_campaign.py, seed 41.)
+    constexpr int T_ROW_BYTES = (PRIV ? U8_WIDE_ROW16 : U8_ROW16) * 16;
     int src[RA_PIECES];
 #pragma unroll
     for (int p = 0; p < RA_PIECES; ++p) {
         const int sl = 64 * p + lane, row = sl / U8_LDS_ROW16, u = sl % U8_LDS_ROW16;
-        if (WSPLIT) src[p] = (sl < 32 * U8_LDS_ROW16 ? sl : 32 * U8_LDS_ROW16 - 1) * 16;
-        else src[p] = (row < 32 ? row : 31) * (U8_ROW16 * 16) + (u < U8_ROW16 ? u : U8_ROW16 - 1) * 16;
+        (void)row; (void)u;
+        src[p] = (sl < 32 * U8_LDS_ROW16 ? sl : 32 * U8_LDS_ROW16 - 1) * 16;
     }
     const __amdgpu_buffer_rsrc_t t_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint4*>(T8), 0, ntiles * (H_TT * T_ROW_BYTES), 0x00020000);
@@ -1296,13 +1305,11 @@ __global__ __launch_bounds__(RA_WAVES * 64, 1) void knn_u8_rega(const uint4* __r
         const uint4* sp = seeds_g + static_cast<size_t>(block0 + blk) * 8 + 4 * h;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if constexpr (WSPLIT) { }                                            // (seeds: with the pieces, read from LDS)
-            else if constexpr (PRIV && ABL::no_ldsread) o.s.v[i] = uint4{0u, 0u, 0u, 0u};   // timing-only build: no seed loads
-            else if constexpr (PRIV) o.s.v[i] = untracked_load16<uint4>(sp + i);  // (waited for by count, with the pieces)
+            if constexpr (PRIV) { }                                              // (seeds: with the pieces, read from LDS)
             else o.s.v[i] = sp[i];
         }
     };
-    constexpr int OPS_PER_BLOCK = RA_PIECES + ((WSPLIT || ABL::no_ldsread) ? 0 : 4);
+    constexpr int OPS_PER_BLOCK = RA_PIECES;                                     // (PRIV: LDS-DMA pieces only)
     ABL::stamp(0);
     Ops o0, o1;
     int b = WSPLIT ? 0 : wave;
@@ -1335,13 +1342,10 @@ __global__ __launch_bounds__(RA_WAVES * 64, 1) void knn_u8_rega(const uint4* __r
         if constexpr (PRIV) {
             // this block's pieces and seeds have landed once at most the next TWO blocks' requests are outstanding
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPS_PER_BLOCK) : "memory");
-            if constexpr (WSPLIT) {
+            {
                 const uint4* sq = mine + buf * RA_PRIV_SLOTS + 4 * h * U8_LDS_ROW16 + U8_ROW16;     // pad slots of rows 4h .. 4h+3
 #pragma unroll
                 for (int i = 0; i < 4; ++i) o.s.v[i] = sq[i * U8_LDS_ROW16];
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) pin_after_wait(o.s.v[i]);
             }
             const uint4* tb = mine + buf * RA_PRIV_SLOTS + r * U8_LDS_ROW16 + h;
 #pragma unroll

@@ -1638,6 +1638,7 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
         const bool fits = (static_cast<long long>(nt) + 3 * H_TT) * (U8_WIDE_ROW16 * 16) < 0x7FFFFFFFLL;   // 32-bit DMA offsets
         if (tps >= 8 && tps <= 16 && fits) ws_splits = sp; else u8_form = 1;
     }
+    if (u8_form == 5 && (static_cast<long long>(nt) + 3 * H_TT) * (U8_WIDE_ROW16 * 16) >= 0x7FFFFFFFLL) u8_form = 1;
     const int qb_wg = u8_form >= 4 ? 128 : (u8_form >= 2 && ctx->opts[PM_OPT_KNN_F16_WAVES] == 3) ? 512 : H_QB;
     const int q_unit = qb_wg > H_QB ? qb_wg : H_QB;           // (a multiple of 256 also when workgroups take 128 queries)
     const int nq_pad = (nq + q_unit - 1) / q_unit * q_unit, nt_pad = (nt + H_TT - 1) / H_TT * H_TT;
@@ -1704,7 +1705,7 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
     const size_t c16 = want16 ? sizeof(float) * static_cast<size_t>(nq) * g16.slots : 0;
     const size_t rowb = u8r ? U8_DP : sizeof(_Float16) * (f16s ? H_DP : dp16 + 16);   // bytes per row of the coarse copies
     const size_t qh = want16 ? rowb * static_cast<size_t>(nq_pad) : 0;
-    const int t_wide = (u8r && u8_form == 6) ? 1 : 0;            // 144-byte train rows with the seeds in the pad slots (knn_u8_rega)
+    const int t_wide = (u8r && u8_form >= 5) ? 1 : 0;            // 144-byte train rows with the seeds in the pad slots (knn_u8_rega)
     const size_t th = want16 ? (t_wide ? static_cast<size_t>(U8_WIDE_ROW16) * 16 : rowb) * static_cast<size_t>(nt_pad) : 0;
     const size_t sdb = (u8r || f16s) ? 4 * static_cast<size_t>(nt_pad + H_TT) : 0;       // seeds (+ one tile of slack)
     const size_t pkb = fuse ? sizeof(unsigned long long) * static_cast<size_t>(nq) : 0;

@@ -199,3 +199,21 @@ def test_u8_route_c3_full_and_32k_slice(ctx, oracle):
     assert st["route"] == 3 and st["rescans"] <= 2 and st["nonfinite"] == 0, st
     planted = truth >= 0
     assert (got["trainIdx"][planted, 0] == truth[planted]).mean() > 0.99
+
+
+def test_low_dimensional_near_ties_every_coarse_form(ctx, oracle):
+    """20-dimensional u8 rows against 33 645 train rows: hundreds of near ties per query, so a coarse pass that ranks on stale
+    operands loses true neighbours (at 128 dimensions the planted matches are too far ahead for that to show).  This is the
+    case tools/fuzz_campaign.py (seed 41) caught the first version of coarse form 5 with: a counted vmcnt wait over a mix of
+    LDS-DMA pieces and register loads returned early — 8 to 70 wrong records per launch, differently on every run."""
+    q, t, _ = synth.sift_like(514, 33645, 20, seed=41)
+    want = oracle.bf_knn_l2(q, t, 2, nthreads=8)
+    q8, t8 = q.astype(np.uint8), t.astype(np.uint8)
+    try:
+        for ring in (5, 6, 2, 3, 4, 1):
+            ctx.set_option(PM_OPT_KNN_RING, ring)
+            for rep in range(4):
+                assert_matches_equal(ctx.bf_knn_l2_u8(q8, t8, 2), want, "u8 rows, coarse form %d, run %d" % (ring, rep))
+            assert_matches_equal(ctx.bf_knn_l2(q, t, 2, PM_KNN_HINT_U8), want, "u8 hint, coarse form %d" % ring)
+    finally:
+        ctx.set_option(PM_OPT_KNN_RING, 0)
