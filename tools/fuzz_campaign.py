@@ -38,6 +38,9 @@ def l2_case(i):
     nq = int(rng.integers(1, 12000 if big else 2500))
     nt = int(rng.integers(1, 40000 if big else 6000))
     k = int(rng.choice([1, 2, 2, 2, 3, 4, 5]))
+    if rng.random() < 0.08:                                  # few dimensions, many train rows: hundreds of near ties per query,
+        dim = int(rng.choice([4, 8, 12, 16, 20, 24]))        # where a coarse pass that ranks on stale operands loses neighbours
+        nq = int(rng.integers(64, 1200)); nt = int(rng.integers(15000, 40000))
     kind = str(rng.choice(["sift", "surf"]))
     q, t, _ = (synth.sift_like if kind == "sift" else synth.surf_like)(nq, nt, dim, seed=int(rng.integers(1 << 30)))
     twist = int(rng.integers(0, 9))
