@@ -10,6 +10,8 @@
 //          [--filter midpoint|ratio] [--ratio 0.8] [--iters 10000] [--thresh 1.0] [--seed 24301]
 //          [--method 7point-lmeds|ransac8] [--f-scale opencv|unit] [--device 0] [--gpus N] [--quiet] [--json]
 //          [--print-epilines] [--epilines out.ppm [--canvas W H] [--img2 right.pgm]] [--matcher bf|flann]
+//          [--knn-hint auto|int|u8]   what the caller knows about float descriptors (pm.h PM_KNN_HINT_*; default auto, and
+//                                     u8 for --img1/--img2, whose extractor writes u8-valued rows): route only, same output
 // --matcher flann: the reference's ACTIVE matcher object (`FlannBasedMatcher matcher;`, main.cpp:44): 4 randomised
 // kd-trees, 32 checks (pm_flann_*; approximate, seeded by --seed); bf (default) is the exact matcher of main.cpp:43.
 // NOTE: the default matcher DEVIATES from main.cpp:44 on purpose — the exact matcher is faster on this hardware at every
@@ -162,7 +164,7 @@ int main(int argc, char** argv)
     long iters = 10000;
     unsigned long long seed = 0x5EED;
     int device = 0, gpus = 1, canvas_w = 993, canvas_h = 660;       // canvas default: the size of img01/img02
-    std::string epi_ppm, img2_path, matcher = "bf", img1_path, save_prefix;
+    std::string epi_ppm, img2_path, matcher = "bf", img1_path, save_prefix, knn_hint;
     bool extract_only = false;
     int max_kp = 4000;
     bool quiet = false, json = false, iters_given = false, print_epi = false, force_mgpu = false;
@@ -186,6 +188,7 @@ int main(int argc, char** argv)
         else if (a == "--device") device = atoi(val("--device"));
         else if (a == "--gpus") gpus = atoi(val("--gpus"));
         else if (a == "--matcher") matcher = val("--matcher");
+        else if (a == "--knn-hint") knn_hint = val("--knn-hint");      // auto | int | u8: what the caller knows about float descriptors
         else if (a == "--mgpu") force_mgpu = true;            // take the pm_mgpu path even with --gpus 1 (tests)
         else if (a == "--print-epilines") print_epi = true;
         else if (a == "--epilines") epi_ppm = val("--epilines");
@@ -201,6 +204,11 @@ int main(int argc, char** argv)
     }
     Matrix d1, d2, k1, k2;
     const bool from_images = !img1_path.empty();
+    // what the caller knows about float descriptors (pm.h: a hint is verified on the device, a wrong one only costs time).
+    // The build-owned extractor of --img1/--img2 writes u8-valued rows, so that path says so unless told otherwise.
+    if (knn_hint.empty()) knn_hint = from_images ? "u8" : "auto";
+    if (knn_hint != "auto" && knn_hint != "int" && knn_hint != "u8") { fprintf(stderr, "pm_cli: --knn-hint auto|int|u8\n"); return 2; }
+    const int knn_flags = knn_hint == "u8" ? PM_KNN_HINT_U8 : (knn_hint == "int" ? PM_KNN_HINT_INTEGER : 0);
     if (from_images) {
         // ---- imread + detect + compute                                          main.cpp:14-15, :22-26, :36-40
         if (img2_path.empty() || max_kp < 8) { fprintf(stderr, "pm_cli: --img1 needs --img2 (and --max-kp >= 8)\n"); return 2; }
@@ -233,7 +241,7 @@ int main(int argc, char** argv)
     if (desc1.empty() || desc2.empty() || kp1.empty() || kp2.empty()) {
         fprintf(stderr, "usage: pm_cli (--img1 L.pgm --img2 R.pgm | --desc1 A --desc2 B --kp1 KA --kp2 KB) [--filter midpoint|ratio] "
                         "[--ratio r] [--method 7point-lmeds|ransac8] [--iters n] [--thresh px] [--seed s] [--f-scale opencv|unit] "
-                        "[--matcher bf|flann] [--gpus N] [--print-epilines] [--epilines out.ppm] [--json] [--quiet]\n"
+                        "[--matcher bf|flann] [--knn-hint auto|int|u8] [--gpus N] [--print-epilines] [--epilines out.ppm] [--json] [--quiet]\n"
                         "  (default matcher bf = exact brute force, main.cpp:43; the reference's active one is --matcher flann, main.cpp:44)\n");
         return 2;
     }
@@ -296,7 +304,7 @@ int main(int argc, char** argv)
         if (rc != PM_OK) return fail("pm_mgpu_create", rc);
         t0 = clk::now();
         rc = pm_mgpu_match_ransac(mg, d1.data.data(), d1.rows, d2.data.data(), d2.rows, d1.cols, d1.dtype == 1, k1.f32(), k2.f32(),
-                                  ratio, 0, &prm, good.data(), &n_good, F, mask.data(), &n_inl, &key);
+                                  ratio, knn_flags, &prm, good.data(), &n_good, F, mask.data(), &n_inl, &key);
         if (rc != PM_OK && rc != PM_E_TOO_FEW && rc != PM_E_NO_MODEL) return fail("pm_mgpu_match_ransac", rc);
         est_rc = rc;
         t1 = t2 = t3 = clk::now();
@@ -319,7 +327,7 @@ int main(int argc, char** argv)
         if (rc == PM_OK) rc = pm_flann_knn_l2_f32(ctx, ix, d1.f32(), d1.rows, k, knn.data());
         pm_flann_destroy(ix);
     } else if (d1.dtype == 0)
-        rc = pm_bf_knn_l2_f32(ctx, d1.f32(), d1.rows, d2.f32(), d2.rows, d1.cols, k, 0, knn.data());
+        rc = pm_bf_knn_l2_f32(ctx, d1.f32(), d1.rows, d2.f32(), d2.rows, d1.cols, k, knn_flags, knn.data());
     else
         rc = pm_bf_knn_hamming_u8(ctx, d1.data.data(), d1.rows, d2.data.data(), d2.rows, d1.cols, k, knn.data());
     if (rc != PM_OK) return fail("matcher", rc);

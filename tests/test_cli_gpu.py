@@ -54,6 +54,27 @@ def test_cli_stdout_matches_reference_format(tmp_path, oracle, mode):
     assert np.array_equal(np.array(js["F"]), F.reshape(9))
 
 
+def test_cli_knn_hint_same_output(tmp_path):
+    """--knn-hint auto | int | u8 on SIFT-like (u8-valued) descriptor files: the hint picks the coarse route, never the result."""
+    exe = build.HOST_BIN
+    w = synth.pair_workload(nq=700, nt=650, dim=128, seed=5, planted=0.5, kind="sift")
+    paths = {}
+    for name in ("q", "t", "kp1", "kp2"):
+        paths[name] = str(tmp_path / (name + ".pmm"))
+        io.save_pmm(paths[name], w[name])
+    outs = []
+    for hint in ("auto", "int", "u8"):
+        cmd = [exe, "--desc1", paths["q"], "--desc2", paths["t"], "--kp1", paths["kp1"], "--kp2", paths["kp2"], "--filter", "ratio",
+               "--method", "ransac8", "--iters", "300", "--seed", "7", "--knn-hint", hint]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        outs.append(out.stdout)
+    assert outs[0] == outs[1] == outs[2] and outs[0].count("result = ") > 100
+    bad = subprocess.run([exe, "--desc1", paths["q"], "--desc2", paths["t"], "--kp1", paths["kp1"], "--kp2", paths["kp2"], "--knn-hint", "x"],
+                         capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 2
+
+
 def test_cli_7point_lmeds_method(tmp_path, oracle):
     """--method 7point-lmeds: what the reference's CV_FM_7POINT call selects (main.cpp:95-98);
     default iteration count = OpenCV's 300."""
