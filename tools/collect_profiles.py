@@ -35,7 +35,7 @@ for txt_name, head in (("mgpu_stream.txt", "tools/mgpu_stream_bench.py: streamed
                        ("sweep_ratio_8192.txt", "tools/sweep_ratio.py 8192 8192: matcher call by route and option"),
                        ("sweep_u8_forms_32k.txt", "tools/sweep_u8.py 32768 32768: the six forms of the u8 coarse kernel (PM_OPT_KNN_RING)"),
                        ("sweep_u8_forms_16k.txt", "tools/sweep_u8.py 16384 16384: tile kernel and register-operand forms 5, 6"),
-                       ("knn_stamps_32k.txt", "tools/prof_knn_stamps.py 32768 32768 on the stamping build: tile kernel and form 6"),
+                       ("knn_stamps_32k.txt", "tools/prof_knn_stamps.py 32768 32768 on the stamping build: ring form (12=2) and split-per-wave form (12=6)"),
                        ("ransac_stamps.txt", "tools/prof_ransac_stamps.py on the stamping build: phase timeline of the one-launch RANSAC kernel, both forms")):
     if os.path.exists(os.path.join(src, txt_name)):
         body = [ln for ln in open(os.path.join(src, txt_name)) if "amdgpu.ids" not in ln]

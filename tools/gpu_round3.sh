@@ -38,7 +38,7 @@ step flann 300 bash -c "python tools/prof_flann.py > $O/flann.txt 2>&1"
 step wide 300 bash -c "python tools/sweep_ratio.py 8192 8192 > $O/sweep_ratio_8192.txt 2>&1"
 step forms32k 300 bash -c "python tools/sweep_u8.py 32768 32768 '' '12=2' '12=3' '12=4' '12=5' '12=6' > $O/sweep_u8_forms_32k.txt 2>&1"
 step forms16k 300 bash -c "python tools/sweep_u8.py 16384 16384 '' '12=5' '12=6' > $O/sweep_u8_forms_16k.txt 2>&1"
-step knnstamps 300 bash -c "for o in '' '12=6'; do echo == options \$o; PM_LIB_PATH=points_matching_amd/build/abl/libpm_knnstamps.so python tools/prof_knn_stamps.py 32768 32768 \$o; done > $O/knn_stamps_32k.txt 2>&1"
+step knnstamps 300 bash -c "for o in '12=2' '12=6'; do echo == options \$o; PM_LIB_PATH=points_matching_amd/build/abl/libpm_knnstamps.so python tools/prof_knn_stamps.py 32768 32768 \$o; done > $O/knn_stamps_32k.txt 2>&1"
 step stamps 200 bash -c "for f in 1 2; do echo == PM_OPT_RANSAC_FORM \$f; PM_RANSAC_FORM=\$f PM_LIB_PATH=points_matching_amd/build/abl/libpm_rfstamps.so python tools/prof_ransac_stamps.py; done > $O/ransac_stamps.txt 2>&1"
 step h2d 200 bash -c "python tools/h2d_ceiling.py > $O/h2d_ceiling.txt 2>&1"
 cd /tmp && export TMPDIR=/tmp

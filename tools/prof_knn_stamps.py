@@ -39,6 +39,10 @@ buf = np.zeros(4096 * 24, np.uint64)
 lib.pm_debug_knn_stamps(buf.ctypes.data_as(C.c_void_p), buf.size)
 s = buf.reshape(4096, 24).astype(np.int64)
 s = s[s[:, 0] != 0]
+if s.shape[0] == 0:
+    print("this coarse-kernel form carries no stamps (the ring forms 12=2 / 12=3 and the register-operand forms 12=5 / 12=6 do)")
+    sys.exit(0)
+rega = any(o.startswith("12=") and int(o[3:]) >= 4 for o in opts)
 rt0, rt1 = s[:, 20], s[:, 21]
 print("workgroups %d; dispatch spread (first -> last entry): %.2f us; kernel span entry(first) -> exit(last): %.2f us" % (
     s.shape[0], (rt0.max() - rt0.min()) / 100.0, (rt1.max() - rt0.min()) / 100.0))
@@ -51,16 +55,17 @@ def show(name, a, b):
     if ok.any():
         d = d[ok]
         print("  %-34s median %7d  p90 %7d  max %7d cycles" % (name, np.median(d), np.percentile(d, 90), d.max()))
-show("entry -> requests issued", 0, 1)
-show("requests issued -> tile 0 ready", 1, 2)
-ntl = int(((s[0, 2:16]) != 0).sum())
-for t in range(1, ntl):
-    show("tile %d (barrier to barrier)" % (t - 1), 1 + t, 2 + t)
-show("last tile + final selection", 1 + ntl, 16)
+show("entry -> %s" % ("query fragments loaded" if rega else "requests issued"), 0, 1)
+if not rega:
+    show("requests issued -> tile 0 ready", 1, 2)
+    ntl = int(((s[0, 2:16]) != 0).sum())
+    for t in range(1, ntl):
+        show("tile %d (barrier to barrier)" % (t - 1), 1 + t, 2 + t)
+    show("last tile + final selection", 1 + ntl, 16)
 show("merge + store", 16, 17)
 xcc = s[:, 22] & 15
 print("workgroups per XCC:", np.bincount(xcc.astype(int), minlength=8).tolist())
-if any(o.startswith("12=") and int(o[3:]) >= 4 for o in opts):
+if rega:
     print("register-operand form: wave 0's 5th..7th block (wait | ds_read+issue | MFMA chain issued | selection issued)")
     for k in range(3):
         b0 = 2 + 4 * k
