@@ -30,6 +30,7 @@
 #include <deque>
 #include <mutex>
 #include <new>
+#include <exception>
 #include <thread>
 #include <vector>
 
@@ -541,7 +542,13 @@ extern "C" int pm_mgpu_create(int n_dev, const int* devices, pm_mgpu** out)
     }
     rc = lane_create(mg, 0);
     if (rc != PM_OK) { (void)pm_mgpu_destroy(mg); return rc; }
-    for (int i = 0; i < n_dev; ++i) mg->dev[i].worker = std::thread(worker_main, mg, &mg->dev[i]);
+    try {                                                    // (the C ABI never throws: a host that cannot start a thread gets a status)
+        for (int i = 0; i < n_dev; ++i) mg->dev[i].worker = std::thread(worker_main, mg, &mg->dev[i]);
+    } catch (const std::exception& e) {
+        pm::set_error("cannot start a worker thread: %s", e.what());
+        (void)pm_mgpu_destroy(mg);                           // (joins the workers that did start)
+        return PM_E_NOMEM;
+    }
     *out = mg;
     return PM_OK;
 }

@@ -275,9 +275,12 @@ extern "C" int pm_batch_run(pm_batch* b, const pm_pair_job* jobs, int n_jobs, fl
     if (T == 1) {
         work(0);
     } else {
-        std::thread other(work, 1);
+        bool started = false;
+        std::thread other;
+        try { other = std::thread(work, 1); started = true; } catch (...) { }     // (the C ABI never throws)
         work(0);
-        other.join();
+        if (started) other.join();
+        else work(1);                                        // no second thread: the calling thread takes the other half too
     }
     for (int t = 0; t < T; ++t)
         if (rcs[t] != PM_OK) { pm::set_error("%s", errs[t]); return rcs[t]; }
