@@ -309,7 +309,8 @@ def main():
     ratio, thresh, seed = 0.8, 1.0, 0x5EED
     # A SIFT matcher knows its descriptors are u8-valued floats: state it, so that only the exact
     # f16-MFMA coarse route is enqueued (the claim is verified on the device).  Other kinds: auto.
-    knn_flags = {"u8": pm.api.PM_KNN_HINT_U8, "int": pm.api.PM_KNN_HINT_INTEGER, "auto": 0}[args.hint] if args.kind == "sift" else 0
+    knn_flags = {"u8": pm.api.PM_KNN_HINT_U8, "int": pm.api.PM_KNN_HINT_INTEGER, "auto": 0}[args.hint] if args.kind == "sift" else \
+        (pm.api.PM_KNN_HINT_UNIT_NORM if args.kind == "surf" and args.hint != "auto" else 0)      # SURF rows are unit-norm
     wseed = 0xC4 if hamming else 0xC3
     nq_total = nq
     if args.scaling == "strong" and world > 1:
@@ -568,28 +569,36 @@ def main():
         g_t = torch.from_numpy(np.ascontiguousarray(wg["t"])).to(dev)
         g_n = torch.zeros(1, dtype=torch.int32, device=dev)
 
-        def gstep():
-            ctx.bf_knn_l2_ratio_dev(g_q.data_ptr(), nq, g_t.data_ptr(), nt, dim, 0, ratio, d_kp1.data_ptr(), d_kp2.data_ptr(),
+        def gstep(gflags=0):
+            ctx.bf_knn_l2_ratio_dev(g_q.data_ptr(), nq, g_t.data_ptr(), nt, dim, gflags, ratio, d_kp1.data_ptr(), d_kp2.data_ptr(),
                                     d_knn.data_ptr(), d_good.data_ptr(), d_xy1.data_ptr(), d_xy2.data_ptr(), g_n.data_ptr())
-        for _ in range(args.warmup):
-            gstep()
-        fence()
-        ge = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        ge[0].record(stream)
-        for _ in range(args.steps):
-            gstep()
-        ge[1].record(stream)
-        fence()
-        g_ms = ge[0].elapsed_time(ge[1]) / args.steps
-        if multi:
-            tt = torch.tensor([g_ms], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            g_ms = float(tt.item())
+
+        def gtime(gflags):
+            for _ in range(args.warmup):
+                gstep(gflags)
+            fence()
+            ge = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ge[0].record(stream)
+            for _ in range(args.steps):
+                gstep(gflags)
+            ge[1].record(stream)
+            fence()
+            ms = ge[0].elapsed_time(ge[1]) / args.steps
+            if multi:
+                tt = torch.tensor([ms], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                ms = float(tt.item())
+            return ms
+        g_ms = gtime(0)                                       # no hint: the automatic route (two prep launches)
+        g_ms_unit = gtime(pm.api.PM_KNN_HINT_UNIT_NORM)       # the caller states ||t|| <= 1 (SURF is): one prep launch
+        g_n_unit = int(g_n.item())
         ctx.knn_diag_enable(True)
         gstep()
         g_st = ctx.knn_stats()
         ctx.knn_diag_enable(False)
         general = {"value": float(nq_total) * nt / (g_ms * 1e-3), "match_ms": g_ms, "matches": int(g_n.item()),
+                   "unit_norm_hint": {"value": float(nq_total) * nt / (g_ms_unit * 1e-3), "match_ms": g_ms_unit, "matches": g_n_unit,
+                                      "note": "PM_KNN_HINT_UNIT_NORM: same records, one prep launch (the bound is verified on the device)"},
                    "descriptors": "surf (unit-norm general floats), automatic route",
                    "coarse_pass": {0: "f16 MFMA, exact integer copies", 1: "f16 MFMA on f16-rounded scaled copies (SPEC S1c)",
                                    2: "f32-input MFMA"}.get(g_st["route"], "?"),
@@ -718,7 +727,9 @@ def main():
                                   "Hamming" if hamming else "L2", H), "descriptors": args.kind, "k": K,
                    "coarse_route": "n/a (Hamming)" if hamming else
                                    {pm.api.PM_KNN_HINT_U8: "i8-MFMA on x - 128 (u8 hint, device-verified)",
-                                    pm.api.PM_KNN_HINT_INTEGER: "f16-MFMA (integer hint, device-verified)"}.get(knn_flags, "auto")},
+                                    pm.api.PM_KNN_HINT_INTEGER: "f16-MFMA (integer hint, device-verified)",
+                                    pm.api.PM_KNN_HINT_UNIT_NORM: "f16-MFMA on rounded scaled copies (unit-norm hint, device-verified: one prep launch)"
+                                    }.get(knn_flags, "auto")},
         "ms_per_step_serial": wall_serial / args.steps * 1e3, "ms_per_step_pipelined": wall_pipe / args.steps * 1e3,
         "step_form": ("pipelined: pair i+1's matcher on a second stream while pair i is in its exchanges / RANSAC" if pipelined
                       else "serial: one pair after the other on one stream"),
@@ -741,6 +752,7 @@ def main():
         out["parity"] = "MISMATCH (the pipeline slots disagree)"
     if general:
         out["value_general_floats"] = general["value"]
+        out["value_general_floats_unit_norm_hint"] = general["unit_norm_hint"]["value"]
         out["general_floats"] = general
     if sustained:
         out["sustained"] = sustained

@@ -159,6 +159,10 @@ int  pm_version(void);                 /* major*100 + minor */
 #define PM_KNN_HINT_U8      8   /* caller states the descriptors are integers in [0, 255] (OpenCV SIFT):  */
                                 /* ranked on the i8 matrix cores (x - 128, 4 k-chunks at D = 128, twice   */
                                 /* the f16 rate).  Verified on the device like PM_KNN_HINT_INTEGER.        */
+#define PM_KNN_HINT_UNIT_NORM 16 /* caller states that every TRAIN row has ||t||^2 <= 1 + 2^-10 (SURF, L2-normalised      */
+                                /* descriptors: what main.cpp:37-40 itself produces): general floats, ranked on the      */
+                                /* f16 matrix pass with ONE prep launch instead of two (the train scale needs no norm    */
+                                /* maximum).  Verified on the device; a wrong hint costs time (exact re-scan).           */
 int pm_bf_knn_l2_f32(pm_ctx* ctx, const float* q, int nq, const float* t, int nt,
                      int dim, int k, int flags, pm_match* out);
 int pm_bf_knn_l2_f32_dev(pm_ctx* ctx, const float* d_q, int nq, const float* d_t, int nt,

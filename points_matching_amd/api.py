@@ -19,6 +19,7 @@ PM_KNN_FORCE_EXACT = 1
 PM_KNN_FORCE_F32 = 2
 PM_KNN_HINT_INTEGER = 4
 PM_KNN_HINT_U8 = 8
+PM_KNN_HINT_UNIT_NORM = 16
 PM_ERR_SAMPSON = 0
 PM_ERR_SYM_EPIPOLAR = 1
 PM_OK, PM_E_INVALID, PM_E_TOO_FEW, PM_E_NO_MODEL, PM_E_HIP, PM_E_NOMEM, PM_E_UNSUPPORTED = \

@@ -591,6 +591,113 @@ __global__ __launch_bounds__(256) void knn_l2_prep16g(const float* __restrict__ 
     }
 }
 
+// The two passes above in ONE launch for data whose scale the caller states (PM_KNN_HINT_UNIT_NORM, round 3): every train
+// row has ||t|| <= 1 (SURF, L2-normalised descriptors: what the reference itself matches, main.cpp:37-40).  The train
+// scale then needs no norm maximum: the bound 1 IS the published maximum (stats[0]), S_t = 2^(10 - h(1)), every query row
+// still gets its own power of two from its own norm, and the premise is verified here — a train row beyond the bound raises
+// the non-finite flag, i.e. every query is scanned exactly (a wrong hint costs time, never a result bit).  Everything
+// downstream (coarse pass, refinement, window) reads the same words as on the automatic route with the bound in place of
+// the measured maximum: the window is the automatic route's whenever the largest train row really has norm 1.
+template <int DP, bool ALIGNED>
+__global__ __launch_bounds__(256) void knn_l2_prep16u(const float* __restrict__ Q, int nq, int nq_pad,
+                                                      const float* __restrict__ T, int nt, int nt_pad, int dim,
+                                                      float* __restrict__ qnorm, float* __restrict__ tnorm,
+                                                      _Float16* __restrict__ Qh, _Float16* __restrict__ Th,
+                                                      unsigned long long* __restrict__ stats, unsigned epoch)
+{
+    typedef F16Rows<DP> G;
+    constexpr int NCB = G::NCB;
+    constexpr float BOUND2 = 1.0009765625f;                 // the stated maximum of ||t||^2: 1, with 2^-10 of slack for rows that
+                                                            // were normalised in f32 (same half-exponent as 1.0)
+    __shared__ unsigned wbad[4];
+    const int ht = half_exp_ceil(BOUND2);
+    const float st = __builtin_ldexpf(1.f, 10 - ht);
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int qblocks = nq_pad / 64;
+    const bool is_t = static_cast<int>(blockIdx.x) >= qblocks;
+    const float* x = is_t ? T : Q;
+    const int n = is_t ? nt : nq;
+    float* norm = is_t ? tnorm : qnorm;
+    _Float16* xh = is_t ? Th : Qh;
+    const int row0 = (is_t ? blockIdx.x - qblocks : blockIdx.x) * 64;
+    const int c0 = 8 * sub;
+    unsigned bad = 0u;
+    Row8<ALIGNED> ld[4][NCB];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = row0 + it * 16 + grp;
+        const float* p = x + static_cast<size_t>(row < n ? row : n - 1) * dim;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) ld[it][cb].load(p, 128 * cb + c0, dim);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = row0 + it * 16 + grp;
+        const bool live = row < n;
+        float s = 0.f;                                      // the row's squared norm, as knn_l2_prep16 computes it
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            float v[8];
+            ld[it][cb].get(128 * cb + c0, dim, live, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s = fmaf(v[e], v[e], s);
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
+        if (live && (!(s < KNN_INF) || (is_t && !(s <= BOUND2)))) bad = 3u;      // not finite, or beyond the stated bound
+        const QueryScale qs = query_scale(ht, s);
+        const float sc = is_t ? st : qs.sq;
+        const bool zero = !live || (!is_t && qs.unranked);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            float v[8];
+            ld[it][cb].get(128 * cb + c0, dim, !zero, v);
+            f16x8 hv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hv[e] = static_cast<_Float16>(v[e] * sc);
+            *reinterpret_cast<f16x8*>(xh + static_cast<size_t>(row) * G::ROWH + 128 * cb + c0) = hv;
+        }
+        if (sub == 0) {
+            if (live) norm[row] = s;
+            f16x8 e0 = {0, 0, 0, 0, 0, 0, 0, 0};
+            const f16x8 e1 = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (is_t) {
+                if (live) {
+                    const float z = __builtin_rintf(s * st * st * 16.f);
+                    const unsigned tn = z < 16777216.f ? static_cast<unsigned>(z) : 16777215u;
+                    e0[0] = static_cast<_Float16>(static_cast<float>(tn >> 13));
+                    e0[1] = static_cast<_Float16>(static_cast<float>((tn >> 6) & 127u));
+                    e0[2] = static_cast<_Float16>(static_cast<float>(tn & 63u));
+                } else {
+                    e0[0] = static_cast<_Float16>(60000.f);
+                    e0[1] = static_cast<_Float16>(60000.f);
+                }
+            } else if (live && qs.unranked) {
+                e0[0] = static_cast<_Float16>(__builtin_nanf(""));
+            } else {
+                e0[0] = static_cast<_Float16>(qs.qc[0]);
+                e0[1] = static_cast<_Float16>(qs.qc[1]);
+                e0[2] = static_cast<_Float16>(qs.qc[2]);
+            }
+            *reinterpret_cast<f16x8*>(xh + static_cast<size_t>(row) * G::ROWH + DP) = e0;
+            *reinterpret_cast<f16x8*>(xh + static_cast<size_t>(row) * G::ROWH + DP + 8) = e1;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bad |= static_cast<unsigned>(__shfl_xor(static_cast<int>(bad), o, 64));
+    if ((threadIdx.x & 63) == 0) wbad[threadIdx.x >> 6] = bad;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long tag = static_cast<unsigned long long>(epoch) << 32;
+        bad = wbad[0] | wbad[1] | wbad[2] | wbad[3];
+        if (blockIdx.x == 0) {
+            atomicMax(&stats[0], tag | f32_bits(BOUND2));   // the "maximum" every later kernel scales and bounds with
+            atomicMax(&stats[1], tag | 2ull);               // general floats (not the integer route)
+        }
+        if (bad) atomicMax(&stats[1], tag | 3ull);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // refinement: one wave per query
 // ---------------------------------------------------------------------------------------------
@@ -1587,7 +1694,9 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
     const int dp16 = dim <= 128 ? 128 : 256;                 // padded columns of the f16 copies
     // automatic route: general floats rank on rounded f16 copies too (SPEC S1c); the f32-input pass is enqueued only when
     // forced (PM_KNN_FORCE_F32) or when PM_OPT_KNN_GENERAL_F16 = 1 keeps it as the automatic route's pass for such data
-    const bool gen32 = route == ROUTE_AUTO && ctx->opts[PM_OPT_KNN_GENERAL_F16] == 1 && narrow;
+    // PM_KNN_HINT_UNIT_NORM: the automatic route's general-float form with its two prep launches in one (knn_l2_prep16u)
+    const bool unit_hint = (flags & PM_KNN_HINT_UNIT_NORM) && route == ROUTE_AUTO;
+    const bool gen32 = route == ROUTE_AUTO && !unit_hint && ctx->opts[PM_OPT_KNN_GENERAL_F16] == 1 && narrow;
     const bool want32 = route == ROUTE_F32 || gen32, want16 = route != ROUTE_F32;
 
     // ---- f32 route geometry: 64-row tiles, 128 queries per workgroup, two workgroups per CU.
@@ -1763,6 +1872,14 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
         else if (f16s)
             hipLaunchKernelGGL((knn_l2_prep16<true, 128, true>), dim3(nq_pad / 64 + nt_pad / 64), dim3(256), 0, ctx->stream, dq, nq,
                                nq_pad, dt, nt, nt_pad, dim, qnorm, tnorm, Qh, Th, static_cast<float*>(seeds), stats, epoch);
+        else if (unit_hint) {
+#define PM_PREP16U(DP_, AL_)                                                                                              \
+    hipLaunchKernelGGL((knn_l2_prep16u<DP_, AL_>), dim3(nq_pad / 64 + nt_pad / 64), dim3(256), 0, ctx->stream, dq, nq, nq_pad, dt, \
+                       nt, nt_pad, dim, qnorm, tnorm, Qh, Th, stats, epoch)
+            if (dp16 == 128) { if (vec) PM_PREP16U(128, true); else PM_PREP16U(128, false); }
+            else { if (vec) PM_PREP16U(256, true); else PM_PREP16U(256, false); }
+#undef PM_PREP16U
+        }
         else if (want16) {
 #define PM_PREP16(DP_, AL_)                                                                                               \
     hipLaunchKernelGGL((knn_l2_prep16<false, DP_, AL_>), dim3(nq_pad / 64 + nt_pad / 64), dim3(256), 0, ctx->stream, dq, nq,    \
@@ -1776,7 +1893,7 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
                                nt, dim, qnorm, tnorm, stats, epoch);
         // automatic route: data that failed the integer premise get f16-ROUNDED scaled copies instead (the train scale
         // needs the norm maximum of the pass above, hence a launch of its own; it returns at once for integer data)
-        if (route == ROUTE_AUTO && !gen32) {
+        if (route == ROUTE_AUTO && !gen32 && !unit_hint) {
 #define PM_PREP16G(DP_, AL_)                                                                                              \
     hipLaunchKernelGGL((knn_l2_prep16g<DP_, AL_>), dim3(nq_pad / 64 + nt_pad / 64), dim3(256), 0, ctx->stream, dq, nq, nq_pad, dt, \
                        nt, nt_pad, dim, qnorm, tnorm, Qh, Th, stats, epoch)

@@ -369,6 +369,43 @@ def test_general_floats_scales(ctx, oracle):
         ctx.set_option(pm.api.PM_OPT_KNN_GENERAL_F16, 0)
 
 
+@pytest.mark.parametrize("nq,nt,dim,k", [(512, 600, 64, 2), (300, 2000, 128, 2), (8192, 8192, 128, 2), (129, 130, 130, 3), (64, 100, 200, 1)])
+def test_unit_norm_hint_one_prep_launch_same_result(ctx, oracle, nq, nt, dim, k):
+    """PM_KNN_HINT_UNIT_NORM: unit-norm general floats (SURF: main.cpp:37-40) through the f16 matrix pass with ONE prep launch.
+    Same records as the automatic route and the oracle; smaller-than-stated norms only widen the window; a train row beyond
+    the bound is detected on the device and every query is scanned exactly."""
+    q, t, _ = synth.surf_like(nq, nt, dim, seed=nq + nt + dim)
+    want = oracle.bf_knn_l2(q, t, k, nthreads=8)
+    H = pm.api.PM_KNN_HINT_UNIT_NORM
+    ctx.knn_diag_enable(True)
+    try:
+        ctx.timing_enable(True); ctx.timing_reset()
+        got = ctx.bf_knn_l2(q, t, k, H)
+        st = ctx.knn_stats()
+        launches = ctx.timing_get("knn_l2_prep")[1]
+        ctx.timing_enable(False)
+        assert_matches_equal(got, want, "unit-norm hint")
+        assert st["route"] == 1 and st["nonfinite"] == 0 and launches == 1, (st, launches)
+        for name, qq, tt in (("train rows at 0.3", q, t * np.float32(0.3)), ("queries x5", q * np.float32(5.0), t),
+                             ("tiny train rows", q, t * np.float32(1e-3)), ("a zero row each", _with_zero_row(q), _with_zero_row(t))):
+            w2 = oracle.bf_knn_l2(qq, tt, k, nthreads=8)
+            assert_matches_equal(ctx.bf_knn_l2(qq, tt, k, H), w2, name)
+            assert ctx.knn_stats()["nonfinite"] == 0, name
+        tt = t.copy(); tt[nt // 2] *= np.float32(1.5)                   # the hint is wrong for one row: exact scan, same answer
+        assert_matches_equal(ctx.bf_knn_l2(q, tt, k, H), oracle.bf_knn_l2(q, tt, k, nthreads=8), "one train row beyond the bound")
+        assert ctx.knn_stats()["nonfinite"] == 1
+        qi, ti, _ = synth.sift_like(min(nq, 400), min(nt, 900), dim if dim % 4 == 0 else 128, seed=3)
+        assert_matches_equal(ctx.bf_knn_l2(qi, ti, k, H), oracle.bf_knn_l2(qi, ti, k, nthreads=8), "integer data under the hint (wrong: norms >> 1)")
+    finally:
+        ctx.knn_diag_enable(False)
+
+
+def _with_zero_row(x):
+    y = x.copy()
+    y[len(y) // 3] = 0.0
+    return y
+
+
 def test_general_floats_near_ties_below_f16_resolution(ctx, oracle):
     """Train rows that differ by less than an f16 ulp: the rounded copies are IDENTICAL, the window must still deliver
     every one of them to the refinement (runs longer than a candidate list force the re-scan branch)."""

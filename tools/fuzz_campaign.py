@@ -81,7 +81,7 @@ def l2_case(i):
     try:
         for o, v in opts.items():
             ctx.set_option(o, v)
-        for flags in (0, A.PM_KNN_HINT_INTEGER, A.PM_KNN_FORCE_F32, A.PM_KNN_HINT_U8):
+        for flags in (0, A.PM_KNN_HINT_INTEGER, A.PM_KNN_FORCE_F32, A.PM_KNN_HINT_U8, A.PM_KNN_HINT_UNIT_NORM):     # (hints right or wrong)
             trace("l2", i, kind, nq, nt, dim, "k", k, "twist", twist, "flags", flags, opts)
             assert_matches_equal(ctx.bf_knn_l2(q, t, k, flags), want,
                                  "L2 case %d: %s %dx%dx%d k=%d twist=%d flags=%d opts=%s" % (i, kind, nq, nt, dim, k, twist, flags, opts))
