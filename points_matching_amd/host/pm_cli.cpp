@@ -10,7 +10,7 @@
 //          [--filter midpoint|ratio] [--ratio 0.8] [--iters 10000] [--thresh 1.0] [--seed 24301]
 //          [--method 7point-lmeds|ransac8] [--f-scale opencv|unit] [--device 0] [--gpus N] [--quiet] [--json]
 //          [--print-epilines] [--epilines out.ppm [--canvas W H] [--img2 right.pgm]] [--matcher bf|flann]
-//          [--knn-hint auto|int|u8]   what the caller knows about float descriptors (pm.h PM_KNN_HINT_*; default auto, and
+//          [--knn-hint auto|int|u8|unit]   what the caller knows about float descriptors (pm.h PM_KNN_HINT_*; default auto, and
 //                                     u8 for --img1/--img2, whose extractor writes u8-valued rows): route only, same output
 // --matcher flann: the reference's ACTIVE matcher object (`FlannBasedMatcher matcher;`, main.cpp:44): 4 randomised
 // kd-trees, 32 checks (pm_flann_*; approximate, seeded by --seed); bf (default) is the exact matcher of main.cpp:43.
@@ -207,8 +207,12 @@ int main(int argc, char** argv)
     // what the caller knows about float descriptors (pm.h: a hint is verified on the device, a wrong one only costs time).
     // The build-owned extractor of --img1/--img2 writes u8-valued rows, so that path says so unless told otherwise.
     if (knn_hint.empty()) knn_hint = from_images ? "u8" : "auto";
-    if (knn_hint != "auto" && knn_hint != "int" && knn_hint != "u8") { fprintf(stderr, "pm_cli: --knn-hint auto|int|u8\n"); return 2; }
-    const int knn_flags = knn_hint == "u8" ? PM_KNN_HINT_U8 : (knn_hint == "int" ? PM_KNN_HINT_INTEGER : 0);
+    if (knn_hint != "auto" && knn_hint != "int" && knn_hint != "u8" && knn_hint != "unit") {
+        fprintf(stderr, "pm_cli: --knn-hint auto|int|u8|unit\n");
+        return 2;
+    }
+    const int knn_flags = knn_hint == "u8" ? PM_KNN_HINT_U8 : knn_hint == "int" ? PM_KNN_HINT_INTEGER :
+                          knn_hint == "unit" ? PM_KNN_HINT_UNIT_NORM : 0;          // unit: L2-normalised rows (SURF, main.cpp:37-40)
     if (from_images) {
         // ---- imread + detect + compute                                          main.cpp:14-15, :22-26, :36-40
         if (img2_path.empty() || max_kp < 8) { fprintf(stderr, "pm_cli: --img1 needs --img2 (and --max-kp >= 8)\n"); return 2; }
@@ -241,7 +245,7 @@ int main(int argc, char** argv)
     if (desc1.empty() || desc2.empty() || kp1.empty() || kp2.empty()) {
         fprintf(stderr, "usage: pm_cli (--img1 L.pgm --img2 R.pgm | --desc1 A --desc2 B --kp1 KA --kp2 KB) [--filter midpoint|ratio] "
                         "[--ratio r] [--method 7point-lmeds|ransac8] [--iters n] [--thresh px] [--seed s] [--f-scale opencv|unit] "
-                        "[--matcher bf|flann] [--knn-hint auto|int|u8] [--gpus N] [--print-epilines] [--epilines out.ppm] [--json] [--quiet]\n"
+                        "[--matcher bf|flann] [--knn-hint auto|int|u8|unit] [--gpus N] [--print-epilines] [--epilines out.ppm] [--json] [--quiet]\n"
                         "  (default matcher bf = exact brute force, main.cpp:43; the reference's active one is --matcher flann, main.cpp:44)\n");
         return 2;
     }

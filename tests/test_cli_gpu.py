@@ -70,6 +70,18 @@ def test_cli_knn_hint_same_output(tmp_path):
         assert out.returncode == 0, out.stderr
         outs.append(out.stdout)
     assert outs[0] == outs[1] == outs[2] and outs[0].count("result = ") > 100
+    # ... and "unit" on unit-norm (SURF-like) rows
+    w = synth.pair_workload(nq=500, nt=450, dim=64, seed=6, planted=0.5, kind="surf")
+    for name in ("q", "t", "kp1", "kp2"):
+        io.save_pmm(paths[name], w[name])
+    outs = []
+    for hint in ("auto", "unit"):
+        cmd = [exe, "--desc1", paths["q"], "--desc2", paths["t"], "--kp1", paths["kp1"], "--kp2", paths["kp2"], "--filter", "ratio",
+               "--method", "ransac8", "--iters", "300", "--seed", "7", "--knn-hint", hint]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        outs.append(out.stdout)
+    assert outs[0] == outs[1] and outs[0].count("result = ") > 50
     bad = subprocess.run([exe, "--desc1", paths["q"], "--desc2", paths["t"], "--kp1", paths["kp1"], "--kp2", paths["kp2"], "--knn-hint", "x"],
                          capture_output=True, text=True, timeout=60)
     assert bad.returncode == 2
