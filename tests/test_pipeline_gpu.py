@@ -177,3 +177,68 @@ def test_fused_matcher_filter_equals_the_two_call_form(ctx, oracle, nq, nt, dim,
         if with_knn:
             knn = d_knn.cpu().numpy().view(pm.MATCH_DTYPE).reshape(nq, 2)
             assert_matches_equal(knn, oracle.bf_knn_l2(w["q"], w["t"], 2, nthreads=8), "records")
+
+
+def test_step_is_stream_capturable_and_the_replay_is_valid():
+    """The device-resident calls of one pair's step neither synchronise nor allocate once warm, so a stream capture of them
+    succeeds; a replay gives the bits of the direct calls, also after other descriptors were copied into the same
+    buffers (hipGraph note: measured slower, kept valid)."""
+    import torch
+    n, H = 1500, 1500
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(device=dev)
+    prev = torch.cuda.current_stream(dev)
+    torch.cuda.set_stream(st)
+    c = pm.Context(0)
+    c.set_stream(st.cuda_stream)
+    try:
+        def upload(seed):
+            w = synth.pair_workload(n, n, 128, seed=seed, kind="sift")
+            return [torch.from_numpy(np.ascontiguousarray(w[k])).to(dev) for k in ("q", "t", "kp1", "kp2")]
+        d_q, d_t, d_kp1, d_kp2 = upload(11)
+        alt = upload(12)
+        knn = torch.empty((n, 2, 4), dtype=torch.int32, device=dev)
+        good = torch.empty((n, 4), dtype=torch.int32, device=dev)
+        cnt = torch.zeros(4, dtype=torch.int32, device=dev)
+        xy1 = torch.empty((n, 2), dtype=torch.float32, device=dev)
+        xy2 = torch.empty((n, 2), dtype=torch.float32, device=dev)
+        key = torch.zeros(1, dtype=torch.int64, device=dev)
+        F = torch.zeros(9, dtype=torch.float64, device=dev)
+        mask = torch.zeros(n, dtype=torch.uint8, device=dev)
+        ninl = torch.zeros(1, dtype=torch.int32, device=dev)
+
+        def step():
+            c.bf_knn_l2_ratio_dev(d_q.data_ptr(), n, d_t.data_ptr(), n, 128, pm.api.PM_KNN_HINT_U8, 0.8, d_kp1.data_ptr(),
+                                  d_kp2.data_ptr(), knn.data_ptr(), good.data_ptr(), xy1.data_ptr(), xy2.data_ptr(), cnt.data_ptr())
+            c.ransac_run_dev(xy1.data_ptr(), xy2.data_ptr(), n, cnt.data_ptr(), 0, H, 1.0, 7, key.data_ptr(), F.data_ptr(),
+                             mask.data_ptr(), ninl.data_ptr())
+
+        def result():
+            torch.cuda.synchronize()
+            m = int(cnt[0])
+            return (m, int(key[0]), int(ninl[0]), F.cpu().numpy().tobytes(), knn.cpu().numpy().tobytes(),
+                    mask.cpu().numpy()[:m].tobytes())
+
+        step()
+        base = result()
+        assert base[0] > 50
+        import gc
+        gc.collect()                     # no finaliser of an earlier test's context (hipFree) inside the capture
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st, capture_error_mode="relaxed"):
+            step()
+        torch.cuda.set_stream(st)
+        knn.zero_(); key.zero_(); F.zero_(); cnt.zero_()
+        g.replay()
+        assert result() == base
+        for dst, src in zip((d_q, d_t, d_kp1, d_kp2), alt):
+            dst.copy_(src)
+        g.replay()
+        replayed = result()
+        step()
+        assert replayed == result() and replayed != base
+        del g
+    finally:
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(prev)
+        c.close()
