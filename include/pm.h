@@ -185,7 +185,11 @@ int pm_bf_knn_l2_u8_ratio_dev(pm_ctx* ctx, const uint8_t* d_q, int nq, const uin
  * pm_bf_knn_l2_f32_dev(k = 2) followed by pm_filter_ratio_gather_dev, bit for bit.  d_knn (nq x 2 records) may be
  * NULL on the MFMA routes: the filter then rides the refinement launch and no record is written (shapes that take
  * the exact kernel — dim % 4 != 0, dim > 128, unaligned rows — need the buffer).  With d_knn the filter is its own
- * launch, which measured faster; PM_OPT_FILTER_FUSION pins either form. */
+ * launch, which measured faster, except with PM_KNN_HINT_U8 up to 768 queries, where the fused launch
+ * is 1.6-2.9 us shorter and is taken; PM_OPT_FILTER_FUSION pins either form.
+ * Graph capture: the matcher and the compaction calls (pm_bf_knn_l2_*, pm_filter_*_gather_dev) pass a per-call epoch
+ * as a kernel argument and therefore return PM_E_UNSUPPORTED on a stream that is capturing (a replay would reuse the
+ * epoch); enqueue them directly — a replay measured slower than direct launches anyway. */
 int pm_bf_knn_l2_ratio_dev(pm_ctx* ctx, const float* d_q, int nq, const float* d_t, int nt, int dim, int flags,
                            float ratio, const float* d_kp1_xy, const float* d_kp2_xy, pm_match* d_knn,
                            pm_match* d_good, float* d_xy1, float* d_xy2, int32_t* d_n_good);

@@ -189,6 +189,7 @@ namespace {
 int fg_prepare(pm_ctx* ctx, int nq, int* nblk)
 {
     *nblk = (nq + FG_ROWS - 1) / FG_ROWS;
+    PM_REFUSE_CAPTURE(ctx);
     PM_REQUIRE(*nblk <= FG_MAX_BLOCKS, PM_E_UNSUPPORTED, "more than 1M query rows per compaction call");
     if (!ctx->fg_counts) {
         // [FG_MAX_BLOCKS] survivor counts + 2 x 64-bit min/max words (8-byte aligned: FG_MAX_BLOCKS is even)

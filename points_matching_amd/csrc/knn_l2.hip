@@ -29,10 +29,13 @@ namespace {
 using namespace pm_knn;
 
 constexpr int TILE_T = 64;    // train rows per LDS tile of the exact kernel
-// u8 route: ratio test + compaction + gather inside the refinement launch?  Measured SLOWER than the separate filter launch at
-// every size (matcher stage, us: C2 19.3 vs 17.7, C3 28.0 vs 27.0, 32k x 32k 143.5 vs 137.9): a kernel boundary costs less than
-// the in-launch look-back behind the slowest workgroup.  The fused form stays selectable (PM_OPT_FILTER_FUSION = 2).
-constexpr bool PM_U8_FUSED_BY_DEFAULT = false;
+// u8 route: ratio test + compaction + gather inside the refinement launch?  A kernel boundary costs about what the in-launch
+// look-back behind the slowest workgroup costs, so from 1024 queries up the two forms measure the same (call, us, two launches
+// / fused: 1024^2 14.95 / 14.83, 2048^2 16.3 / 16.2, 8192^2 26.5 / 26.1) and the separate launch stays the default; up to 512
+// queries (<= 32 workgroups, one look-back hop) the fused form is 1.6-1.8 us shorter (512^2 15.1 / 13.3, 128^2 14.1 / 12.4;
+// tools/small_fusion.py) and is the default.  PM_OPT_FILTER_FUSION pins either form.
+constexpr int PM_U8_FUSED_MAX_NQ = 768;
+__host__ inline bool u8_fused_by_default(int nq) { return nq <= PM_U8_FUSED_MAX_NQ; }
 constexpr float KNN_INF = __builtin_inff();
 
 __device__ __forceinline__ uint32_t f32_bits(float f) { return __float_as_uint(f); }
@@ -1845,6 +1848,7 @@ int knn_l2_enqueue(pm_ctx* ctx, const float* dq, int nq, const float* dt, int nt
     g16.cand = cval16;
 
     unsigned long long* stats = ctx->knn_stats;          // persistent, epoch-tagged: never cleared
+    PM_REFUSE_CAPTURE(ctx);
     if (++ctx->knn_epoch == 0u) {              // 2^32 calls: restart the epoch tags
         PM_HIP_CHECK(hipMemsetAsync(stats, 0, 32, ctx->stream));
         ctx->knn_epoch = 1u;
@@ -2010,7 +2014,7 @@ extern "C" int pm_bf_knn_l2_ratio_dev(pm_ctx* ctx, const float* d_q, int nq, con
     // workgroup and a look-back — PM_OPT_FILTER_FUSION = 0 takes the form that measured faster there.
     const int fusion = ctx->opts[PM_OPT_FILTER_FUSION];
     const bool u8_hint = (flags & PM_KNN_HINT_U8) && !(flags & (PM_KNN_FORCE_F32 | PM_KNN_FORCE_EXACT));
-    const bool separate = fusion == 1 || (fusion == 0 && d_knn != nullptr && !(u8_hint && PM_U8_FUSED_BY_DEFAULT));
+    const bool separate = fusion == 1 || (fusion == 0 && d_knn != nullptr && !(u8_hint && u8_fused_by_default(nq)));
     int rc;
     if (!separate) {
         rc = knn_l2_enqueue(ctx, d_q, nq, d_t, nt, dim, 2, flags, d_knn, &fz);
@@ -2082,7 +2086,7 @@ extern "C" int pm_bf_knn_l2_u8_ratio_dev(pm_ctx* ctx, const uint8_t* d_q, int nq
         return PM_OK;
     }
     const int fusion = ctx->opts[PM_OPT_FILTER_FUSION];
-    if (fusion == 2 || (fusion == 0 && PM_U8_FUSED_BY_DEFAULT)) {
+    if (fusion == 2 || (fusion == 0 && u8_fused_by_default(nq))) {
         KnnFuse fz{};
         fz.ratio = ratio; fz.kp1 = d_kp1_xy; fz.kp2 = d_kp2_xy; fz.good = d_good; fz.xy1 = d_xy1; fz.xy2 = d_xy2; fz.n_out = d_n_good;
         const int rf = nt >= 1 ? knn_l2_enqueue(ctx, nullptr, nq, nullptr, nt, dim, 2, 0, d_knn, &fz, d_q, d_t) : 2;

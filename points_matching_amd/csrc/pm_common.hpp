@@ -35,6 +35,18 @@ void set_error(const char* fmt, ...);
         }                                                                               \
     } while (0)
 
+// The matcher and the compaction kernels tag their side-band words with a per-call epoch that the HOST increments (it
+// stands in for a memset per call).  A captured graph freezes that argument: a replay could take the previous replay's
+// look-back counts for its own.  So these calls refuse a capturing stream instead of recording something unreplayable.
+inline bool stream_is_capturing(hipStream_t s)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+}
+#define PM_REFUSE_CAPTURE(ctx_)                                                                                         \
+    PM_REQUIRE(!::pm::stream_is_capturing((ctx_)->stream), PM_E_UNSUPPORTED,                                            \
+               "the stream is capturing a graph: this call carries a per-call epoch argument and cannot be replayed")
+
 struct KernelTimer {
     double total_ms = 0.0;
     int launches = 0;

@@ -1,7 +1,8 @@
 """hipGraph replay of one image pair's step (matcher + ratio filter + RANSAC, all device-resident calls of the C ABI)
 against the same calls enqueued directly: time per step, and whether a REPLAY is valid at all — the launches carry
 host-incremented epoch arguments (they stand in for per-call memsets of the side-band words), which a captured graph
-freezes.      python tools/graph_step.py [n hyps]"""
+freezes.  The record under profiles/ was taken before those calls learned to refuse a capturing stream (PM_REFUSE_CAPTURE);
+with the library as it is now this prints "capture refused".      python tools/graph_step.py [n hyps]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
