@@ -12,7 +12,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libpm_oracle.so")
+# PM_ORACLE_LIB: another build of the same source (oracle/Makefile `sanitize`: AddressSanitizer + UBSan), tests only
+_LIB_PATH = os.environ.get("PM_ORACLE_LIB") or os.path.join(_HERE, "libpm_oracle.so")
 
 MATCH_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"),
                         ("distance", "<f4")])
@@ -24,6 +25,8 @@ class RansacParams(C.Structure):
 
 
 def build(force=False):
+    if os.environ.get("PM_ORACLE_LIB"):
+        return _LIB_PATH
     if force or not os.path.exists(_LIB_PATH) or \
             os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "pm_oracle.c")):
         subprocess.check_call(["make", "-C", _HERE, "-s"])

@@ -87,6 +87,22 @@ def build_host(force=False):
     return HOST_BIN
 
 
+def build_host_sanitized():
+    """The host tool under AddressSanitizer + UBSan (tests/test_oracle_sanitized_cpu.py: the feature front-end is the
+    host code with the most index arithmetic).  CPU only; never shipped."""
+    out = os.path.join(HERE, "build", "pm_cli_san")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    deps = HOST_SRCS + [os.path.join(HOST_DIR, "pm_features.hpp"), os.path.join(ROOT, "include", "pm.h"), LIB]
+    if any(_newer(d, out) for d in deps):
+        cmd = ["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+               "-fno-omit-frame-pointer", "-I" + os.path.join(ROOT, "include"), "-I" + HOST_DIR] + HOST_SRCS + \
+              ["-o", out, "-L" + HERE, "-lpm_hip", "-Wl,-rpath," + HERE]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("sanitized host build failed:\n%s\n%s" % (" ".join(cmd), r.stderr))
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))
     print(build_host(force="--force" in sys.argv))
