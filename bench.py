@@ -112,6 +112,8 @@ def bench_c5(args, world, rank, local_rank, dev, multi, saved_stdout):
     batch.set_option(pm.api.PM_OPT_RANSAC_PATH, args.ransac_path)
     if args.ransac_wg_ids >= 0:
         batch.set_option(pm.api.PM_OPT_RANSAC_WG_IDS, args.ransac_wg_ids)
+    if args.c5_filter_fusion:
+        batch.set_option(pm.api.PM_OPT_FILTER_FUSION, args.c5_filter_fusion)
     batch.set_host_threads(args.c5_host_threads)
     batch.set_desc_u8(u8)
     arr = batch.make_jobs(jobs)
@@ -243,6 +245,8 @@ def main():
     ap.add_argument("--single-device", action="store_true", help="debugging: every rank uses cuda:0")
     ap.add_argument("--c5-host-threads", type=int, default=0, choices=[0, 1, 2],
                     help="c5: host threads enqueueing the pairs (0: automatic = 2 with >= 4 lanes)")
+    ap.add_argument("--c5-filter-fusion", type=int, default=0, choices=[0, 1, 2],
+                    help="c5: PM_OPT_FILTER_FUSION on every lane (0 = the library's choice, 1 = filter as its own launch, 2 = inside the refinement)")
     ap.add_argument("--ransac-wg-ids", type=int, default=-1,
                     help="c5: hypothesis ids per RANSAC workgroup (-1: the batch's default, 32; 0: spread over all CUs)")
     ap.add_argument("--ransac-path", type=int, default=0, choices=[0, 1, 2],
